@@ -1,0 +1,391 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference); the GPU box and the test
+suite only ever read the committed ``*.npz`` / ``*.json`` outputs.  The reference's
+source never travels: this script imports it in place (see _refshim.py) and stores
+inputs, seeds, weights of the tiny configurations and the reference's outputs.
+
+    python tests/golden/make_golden.py            # regenerates every fixture
+    python tests/golden/make_golden.py --skip-large   # tiny fixtures only
+
+What is pinned:
+  tiny_u / tiny_u_cond / tiny_t2i   full state_dict + (x, t[, ctx|y]) -> out + per-stage
+                                    intermediates of libs/uvit.py:306 / libs/uvit_t2i.py:308
+  hooks_u                           libs/dissection.py:115 u-space hook (head/tail through the
+                                    reference itself; mid through the reference's blocks with
+                                    the add applied by a forward hook, because the reference's
+                                    own reader raises EinopsError on [n,L,D] deltas)
+  p2p_t2i                           tools/utils_t2i.py:265 attention-map hook
+  big_{S,L}_{u,t}                   seed-regenerated weights (sha256 pinned) -> out, B=2
+  euler20_S_u                       BASELINE config 1: 20 fixed Euler steps, B=4, driven by
+                                    a plain loop written here around the reference nnet
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _refshim  # noqa: E402
+
+WEIGHT_SEED = 1234
+INPUT_SEED = 7
+
+SHAPES = {
+    "S": dict(embed_dim=512, depth=16, num_heads=8),
+    "L": dict(embed_dim=1024, depth=20, num_heads=16),
+}
+COMMON = dict(img_size=32, patch_size=2, in_chans=4, mlp_ratio=4, qkv_bias=False, mlp_time_embed=False)
+
+
+def sd_numpy(model):
+    return {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+
+
+def sd_sha256(model):
+    h = hashlib.sha256()
+    for k, v in model.state_dict().items():
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(v.detach().cpu().numpy()).tobytes())
+    return h.hexdigest()
+
+
+def expand_t(tval, B):
+    # flow_matching.py:30-34: 0-d t expanded to (B,) with stride 0
+    return torch.tensor(tval, dtype=torch.float32).expand(B)
+
+
+class Tap:
+    """Forward hooks that record module outputs (and the first block's input)."""
+
+    def __init__(self, model):
+        self.store = {}
+        self.handles = []
+        m = model
+        self._pre(m.in_blocks[0], "tok")
+        for i, b in enumerate(m.in_blocks):
+            self._post(b, f"in{i}")
+        self._post(m.mid_block, "mid")
+        for i, b in enumerate(m.out_blocks):
+            self._post(b, f"out{i}")
+        self._post(m.norm, "norm")
+        self._post(m.decoder_pred, "dec")
+        b0 = m.in_blocks[0]
+        self._post(b0.norm1, "b0_norm1")
+        self._post(b0.attn.qkv, "b0_qkv")
+        self._post(b0.attn, "b0_attn")
+        self._post(b0.mlp.fc1, "b0_fc1")
+        self._post(b0.mlp, "b0_mlp")
+        o0 = m.out_blocks[0]
+        self._post(o0.skip_linear, "o0_skip")
+
+    def _pre(self, mod, name):
+        def fn(_m, args, kwargs=None):
+            self.store[name] = args[0].detach().clone().numpy()
+
+        self.handles.append(mod.register_forward_pre_hook(fn))
+
+    def _post(self, mod, name):
+        def fn(_m, _a, out):
+            self.store[name] = out.detach().clone().numpy()
+
+        self.handles.append(mod.register_forward_hook(fn))
+
+    def close(self):
+        for h in self.handles:
+            h.remove()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez(path, **arrays)
+    print(f"wrote {name}: {os.path.getsize(path)/1024:.1f} KiB")
+
+
+# --------------------------------------------------------------------------- tiny configs
+TINY = dict(img_size=16, patch_size=2, in_chans=4, embed_dim=64, depth=2, num_heads=1,
+            mlp_ratio=4, qkv_bias=False, mlp_time_embed=False)
+
+
+def make_tiny_u(uvit):
+    torch.manual_seed(WEIGHT_SEED)
+    m = uvit.UViT(num_classes=-1, **TINY).eval()
+    g = torch.Generator().manual_seed(INPUT_SEED)
+    x = torch.randn(3, 4, 16, 16, generator=g)
+    out = {f"sd/{k}": v for k, v in sd_numpy(m).items()}
+    out["x"] = x.numpy()
+    tvals = [0.0, 0.3, 1.0]
+    out["tvals"] = np.array(tvals, np.float32)
+    for i, tv in enumerate(tvals):
+        tap = Tap(m)
+        with torch.no_grad():
+            o, aux = m(x, expand_t(tv, 3), None, edit_loc=None)
+        assert aux is None
+        tap.close()
+        out[f"out{i}"] = o.numpy()
+        if i == 1:
+            for k, v in tap.store.items():
+                out[f"tap/{k}"] = v
+    save("tiny_u.npz", **out)
+    return m, x
+
+
+def make_tiny_u_cond(uvit):
+    torch.manual_seed(WEIGHT_SEED + 1)
+    m = uvit.UViT(num_classes=10, **TINY).eval()
+    g = torch.Generator().manual_seed(INPUT_SEED)
+    x = torch.randn(3, 4, 16, 16, generator=g)
+    y = torch.tensor([0, 7, 3], dtype=torch.int64)
+    tap = Tap(m)
+    with torch.no_grad():
+        o, _ = m(x, expand_t(0.55, 3), y, edit_loc=None)
+    tap.close()
+    out = {f"sd/{k}": v for k, v in sd_numpy(m).items()}
+    out.update(x=x.numpy(), y=y.numpy(), tval=np.float32(0.55), out=o.numpy(), tok=tap.store["tok"])
+    save("tiny_u_cond.npz", **out)
+
+
+def make_tiny_t2i(uvit_t2i):
+    torch.manual_seed(WEIGHT_SEED + 2)
+    cfg = dict(TINY)
+    m = uvit_t2i.UViT(clip_dim=32, num_clip_token=77, **cfg).eval()
+    g = torch.Generator().manual_seed(INPUT_SEED)
+    x = torch.randn(3, 4, 16, 16, generator=g)
+    ctx = torch.randn(3, 77, 32, generator=g)
+    out = {f"sd/{k}": v for k, v in sd_numpy(m).items()}
+    out.update(x=x.numpy(), ctx=ctx.numpy())
+    tvals = [0.0, 0.62]
+    out["tvals"] = np.array(tvals, np.float32)
+    for i, tv in enumerate(tvals):
+        tap = Tap(m)
+        with torch.no_grad():
+            o, _ = m(x, expand_t(tv, 3), context=ctx)
+        tap.close()
+        out[f"out{i}"] = o.numpy()
+        if i == 1:
+            for k, v in tap.store.items():
+                out[f"tap/{k}"] = v
+    save("tiny_t2i.npz", **out)
+    return m, x, ctx
+
+
+# --------------------------------------------------------------------------- u-space hook
+def make_hooks_u(uvit, m, x):
+    """libs/dissection.py:115-186 through libs/uvit.py:313,336,349."""
+    rng = np.random.default_rng(11)
+    L, D = 65, 64
+    out = {}
+    cases = []
+    with tempfile.TemporaryDirectory() as d:
+        # image-shaped deltas (head / tail): [n_attr, C, H, W]; token-shaped (mid): [n_attr, L, D]
+        img_attr = (rng.standard_normal((5, 4, 16, 16)) * 0.3).astype(np.float32)
+        img_pca = (rng.standard_normal((4, 4, 16, 16)) * 0.3).astype(np.float32)
+        tok_attr = (rng.standard_normal((5, L, D)) * 0.3).astype(np.float32)
+        for ts in ("0.00", "0.20", "0.40", "0.41"):
+            np.save(os.path.join(d, f"delta_{ts}.npy"), img_attr)
+            np.save(os.path.join(d, f"pca4_{ts}.npy"), img_pca)
+        out["img_attr"], out["img_pca"], out["tok_attr"] = img_attr, img_pca, tok_attr
+
+        def run(**kw):
+            base = dict(dissect_task="uspace_uvit", t_edit=0.4, write_path_root=d)
+            base.update(kw)
+            tv = base.pop("tval")
+            with torch.no_grad():
+                o, _ = m(x, expand_t(tv, x.shape[0]), None, **base)
+            return o.numpy()
+
+        spec = [
+            dict(edit_loc="head", dissect_name="write_attr", ith_attr=2, write_scale=1.0, tval=0.2),
+            dict(edit_loc="head", dissect_name="write_attr", ith_attr="1_3", write_scale=-2.0, tval=0.2),
+            dict(edit_loc="tail", dissect_name="write_attr", ith_attr=4, write_scale=0.5, tval=0.2),
+            dict(edit_loc="tail", dissect_name="write_attr", ith_attr="0_2_4", write_scale=1.5, tval=0.4),
+            dict(edit_loc="head", dissect_name="write_pca", ith_component=3, pca_n=4, write_scale=2.0, tval=0.2),
+            dict(edit_loc="tail", dissect_name="write_pca", ith_component=0, pca_n=4, write_scale=-1.0, tval=0.2),
+            # skipped edits: t formats to "0.00" (libs/dissection.py:22) / t > t_edit
+            dict(edit_loc="head", dissect_name="write_attr", ith_attr=2, write_scale=1.0, tval=0.004),
+            dict(edit_loc="tail", dissect_name="write_attr", ith_attr=2, write_scale=1.0, tval=0.41),
+            # 0.404 formats to "0.40" <= t_edit: still edited (dopri5-stage rounding case)
+            dict(edit_loc="head", dissect_name="write_attr", ith_attr=2, write_scale=1.0, tval=0.404),
+            # write_scale 0 == no hook
+            dict(edit_loc="head", dissect_name="write_attr", ith_attr=2, write_scale=0.0, tval=0.2),
+            # unknown edit_loc string is a no-op
+            dict(edit_loc="nowhere", dissect_name="write_attr", ith_attr=2, write_scale=1.0, tval=0.2),
+            # "every_0.2" string t_edit
+            dict(edit_loc="head", dissect_name="write_attr", ith_attr=1, write_scale=1.0, tval=0.4, t_edit="every_0.2"),
+        ]
+        for i, s in enumerate(spec):
+            out[f"case{i}"] = run(**s)
+            cases.append({k: v for k, v in s.items()})
+
+        # mid: reference reader raises on [n,L,D]; apply the documented add with a forward hook
+        def mid_case(ith, scale, tv):
+            sel = tok_attr[ith] if isinstance(ith, int) else np.mean(
+                [tok_attr[int(a)] for a in ith.split("_")], axis=0)
+            add = torch.from_numpy(sel.astype(np.float32))[None] * scale
+            h = m.mid_block.register_forward_hook(lambda _m, _a, o: o + add)
+            with torch.no_grad():
+                o, _ = m(x, expand_t(tv, x.shape[0]), None, edit_loc=None)
+            h.remove()
+            return o.numpy()
+
+        out["mid0"] = mid_case(2, 1.0, 0.2)
+        out["mid1"] = mid_case("1_3", -0.5, 0.2)
+
+        # read mode: file naming + content (libs/dissection.py:126-136)
+        rd = os.path.join(d, "read")
+        with torch.no_grad():
+            m(x, expand_t(0.37, 3), None, edit_loc="tail", dissect_task="uspace_uvit",
+              dissect_name="read", read_path_root=rd, batch_id=5)
+        names = sorted(os.listdir(rd))
+        assert names == ["5_0.37.npy"], names
+        out["read_tail"] = np.load(os.path.join(rd, names[0]))
+
+        # error convention: unknown dissect_name -> ValueError (libs/dissection.py:182)
+        try:
+            run(edit_loc="head", dissect_name="bogus", tval=0.2)
+            raise SystemExit("expected ValueError")
+        except ValueError:
+            pass
+    out["cases_json"] = np.frombuffer(json.dumps(cases).encode(), dtype=np.uint8)
+    save("hooks_u.npz", **out)
+
+
+# --------------------------------------------------------------------------- attention-map hook
+def make_p2p_t2i(m, x, ctx):
+    """tools/utils_t2i.py:265-296 through libs/uvit_t2i.py:91-107."""
+    B = x.shape[0]
+    ids_a = [np.array([3, 5], dtype=np.int64), np.array([], dtype=np.int64), np.array([0, 76, 76], dtype=np.int64)]
+    spec = [
+        dict(dissect_name="p2p", fm_direction="decode", t_edit=0.5, tval=0.3, block_id="all",
+             token_kwargs=dict(token_dissect="p2p_rescale", p2p_multiplier=3.0), ids="a"),
+        dict(dissect_name="p2p", fm_direction="decode", t_edit=0.5, tval=0.3, block_id=[1, 2],
+             token_kwargs=dict(token_dissect="p2p_rescale", p2p_multiplier=[0.0, 5.0, 2.5]), ids="a"),
+        dict(dissect_name="local_prompt", fm_direction="decode", t_edit=0.5, tval=0.3, block_id=0,
+             token_kwargs=dict(token_dissect="p2p_rescale", p2p_multiplier=4), ids="a"),
+        dict(dissect_name="p2p", fm_direction="decode", t_edit=0.5, tval=0.3, block_id=None,
+             token_kwargs=dict(token_dissect="p2p_rescale", p2p_multiplier=0.25), ids="a"),
+        # not edited: encode direction / t above t_edit / lp_* token_dissect / multiplier 1
+        dict(dissect_name="p2p", fm_direction="encode", t_edit=0.5, tval=0.3, block_id="all",
+             token_kwargs=dict(token_dissect="p2p_rescale", p2p_multiplier=3.0), ids="a"),
+        dict(dissect_name="p2p", fm_direction="decode", t_edit=0.5, tval=0.51, block_id="all",
+             token_kwargs=dict(token_dissect="p2p_rescale", p2p_multiplier=3.0), ids="a"),
+        dict(dissect_name="sampled_image_editing", fm_direction="decode", t_edit=0.5, tval=0.3, block_id="all",
+             token_kwargs=dict(token_dissect="lp_anything", p2p_multiplier=3.0), ids="a"),
+        dict(dissect_name="p2p", fm_direction="decode", t_edit=0.5, tval=0.3, block_id="all",
+             token_kwargs=dict(token_dissect="p2p_rescale", p2p_multiplier=1.0), ids="a"),
+    ]
+    out = {"ids_a0": ids_a[0], "ids_a1": ids_a[1], "ids_a2": ids_a[2]}
+    cases = []
+    for i, s in enumerate(spec):
+        kw = dict(s)
+        tv = kw.pop("tval")
+        kw.pop("ids")
+        kw["target_context_ids"] = [a.copy() for a in ids_a]
+        with torch.no_grad():
+            o, _ = m(x, expand_t(tv, B), context=ctx, **kw)
+        out[f"case{i}"] = o.numpy()
+        cases.append(s)
+    out["cases_json"] = np.frombuffer(json.dumps(cases).encode(), dtype=np.uint8)
+    save("p2p_t2i.npz", **out)
+
+
+# --------------------------------------------------------------------------- S / L shapes
+def build_big(uvit, uvit_t2i, shape, kind):
+    torch.manual_seed(WEIGHT_SEED)
+    if kind == "u":
+        return uvit.UViT(num_classes=-1, **COMMON, **SHAPES[shape]).eval()
+    return uvit_t2i.UViT(clip_dim=768, num_clip_token=77, **COMMON, **SHAPES[shape]).eval()
+
+
+def make_big(uvit, uvit_t2i, timing):
+    for shape in ("S", "L"):
+        for kind in ("u", "t"):
+            m = build_big(uvit, uvit_t2i, shape, kind)
+            g = torch.Generator().manual_seed(INPUT_SEED)
+            B = 2
+            x = torch.randn(B, 4, 32, 32, generator=g)
+            ctx = torch.randn(B, 77, 768, generator=g)
+            tv = 0.35
+            with torch.no_grad():
+                t0 = time.perf_counter()
+                if kind == "u":
+                    o, _ = m(x, expand_t(tv, B), None, edit_loc=None)
+                else:
+                    o, _ = m(x, expand_t(tv, B), context=ctx)
+                dt = time.perf_counter() - t0
+            sd = m.state_dict()
+            probe = {k: float(v.double().sum()) for k, v in list(sd.items())[:6]}
+            meta = dict(shape=shape, kind=kind, weight_seed=WEIGHT_SEED, input_seed=INPUT_SEED, tval=tv,
+                        sha256=sd_sha256(m), n_params=int(sum(p.numel() for p in m.parameters())),
+                        probe_sums=probe, torch=torch.__version__)
+            save(f"big_{shape}_{kind}.npz", x=x.numpy(), ctx=ctx.numpy().astype(np.float32) if kind == "t" else np.zeros(0, np.float32),
+                 out=o.numpy(), meta_json=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
+            timing[f"fwd_{shape}_{kind}_B2_first_call_s"] = dt
+            if shape == "L" and kind == "u":
+                # BASELINE config 2 CPU figure: timed B=8 forward, extrapolated linearly in B and NFE
+                x8 = torch.randn(8, 4, 32, 32, generator=g)
+                reps = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    m(x8, expand_t(tv, 8), None, edit_loc=None)
+                    reps.append(time.perf_counter() - t0)
+                timing["fwd_L_u_B8_s_min_of_3"] = float(min(reps))
+                timing["cfg2_L_u_B64_dopri5_50_images_per_s_extrapolated"] = 8.0 / (min(reps) * 301)
+                timing["cfg2_L_u_B64_euler50_images_per_s_extrapolated"] = 8.0 / (min(reps) * 50)
+            del m
+
+
+def make_euler20(uvit, timing):
+    """BASELINE.json configs[0]: S-deep16, 20 Euler steps, B=4, random-init, CPU reference."""
+    m = build_big(uvit, None, "S", "u")
+    g = torch.Generator().manual_seed(INPUT_SEED)
+    z = torch.randn(4, 4, 32, 32, generator=g)
+    n = 20
+    h = np.float32(1.0) / np.float32(n)
+    y = z.clone()
+    per = []
+    with torch.no_grad():
+        for k in range(n):
+            tk = np.float32(k) * h
+            t0 = time.perf_counter()
+            v, _ = m(y, expand_t(float(tk), 4), None, edit_loc=None)
+            per.append(time.perf_counter() - t0)
+            y = y + float(h) * v
+    save("euler20_S_u.npz", z=z.numpy(), x1=y.numpy(), n_steps=np.int32(n))
+    timing["cfg1_S_u_B4_euler20_total_s"] = float(np.sum(per))
+    timing["cfg1_S_u_B4_fwd_median_s"] = float(np.median(per))
+    timing["cfg1_images_per_s"] = 4.0 / float(np.sum(per))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-large", action="store_true")
+    args = ap.parse_args()
+    uvit, uvit_t2i = _refshim.load_reference()
+    torch.set_grad_enabled(False)
+    m, x = make_tiny_u(uvit)
+    make_hooks_u(uvit, m, x)
+    make_tiny_u_cond(uvit)
+    mt, xt, ctx = make_tiny_t2i(uvit_t2i)
+    make_p2p_t2i(mt, xt, ctx)
+    if not args.skip_large:
+        timing = dict(threads=torch.get_num_threads(), nproc=os.cpu_count(),
+                      cpu=[l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0],
+                      torch=torch.__version__, dtype="float32", note="reference PyTorch-CPU path, this container")
+        make_big(uvit, uvit_t2i, timing)
+        make_euler20(uvit, timing)
+        with open(os.path.join(HERE, "ref_cpu_timing.json"), "w") as f:
+            json.dump(timing, f, indent=1)
+        print(json.dumps(timing, indent=1))
+
+
+if __name__ == "__main__":
+    main()
