@@ -1,0 +1,125 @@
+"""Pin the CPU oracle (oracle/) against the golden vectors produced by importing the reference."""
+import json
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from oracle import uvit_oracle as O
+
+TINY = dict(img_size=16, patch_size=2, in_chans=4, embed_dim=64, depth=2, num_heads=1)
+TOL = dict(rtol=2e-5, atol=2e-5)
+
+
+def _load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name))
+    sd = {k[3:]: z[k] for k in z.files if k.startswith("sd/")}
+    return z, sd
+
+
+def test_tiny_u_outputs_and_taps(golden_dir):
+    z, sd = _load(golden_dir, "tiny_u.npz")
+    spec = O.UViTSpec(**TINY)
+    for i, tv in enumerate(z["tvals"]):
+        taps = {}
+        out = O.uvit_forward(spec, sd, z["x"], tv, taps=taps, edit_loc=None)
+        np.testing.assert_allclose(out, z[f"out{i}"], **TOL)
+        if i == 1:
+            for k in [f for f in z.files if f.startswith("tap/")]:
+                name = k[4:]
+                assert name in taps, name
+                np.testing.assert_allclose(taps[name], z[k], err_msg=name, **TOL)
+
+
+def test_tiny_u_cond_label_token_order(golden_dir):
+    z, sd = _load(golden_dir, "tiny_u_cond.npz")
+    spec = O.UViTSpec(num_classes=10, **TINY)
+    assert spec.extras == 2
+    taps = {}
+    out = O.uvit_forward(spec, sd, z["x"], z["tval"], y=z["y"], taps=taps, edit_loc=None)
+    np.testing.assert_allclose(taps["tok"], z["tok"], **TOL)
+    np.testing.assert_allclose(out, z["out"], **TOL)
+
+
+def test_tiny_t2i_outputs_and_taps(golden_dir):
+    z, sd = _load(golden_dir, "tiny_t2i.npz")
+    spec = O.UViTSpec(t2i=True, clip_dim=32, num_clip_token=77, **TINY)
+    assert spec.L == 142
+    for i, tv in enumerate(z["tvals"]):
+        taps = {}
+        out = O.uvit_forward(spec, sd, z["x"], tv, context=z["ctx"], taps=taps)
+        np.testing.assert_allclose(out, z[f"out{i}"], **TOL)
+        if i == 1:
+            for k in [f for f in z.files if f.startswith("tap/")]:
+                np.testing.assert_allclose(taps[k[4:]], z[k], err_msg=k, **TOL)
+
+
+def test_uspace_hook_cases(golden_dir):
+    zt, sd = _load(golden_dir, "tiny_u.npz")
+    z = np.load(os.path.join(golden_dir, "hooks_u.npz"))
+    cases = json.loads(bytes(z["cases_json"]).decode())
+    spec = O.UViTSpec(**TINY)
+    with tempfile.TemporaryDirectory() as d:
+        for ts in ("0.00", "0.20", "0.40", "0.41"):
+            np.save(os.path.join(d, f"delta_{ts}.npy"), z["img_attr"])
+            np.save(os.path.join(d, f"pca4_{ts}.npy"), z["img_pca"])
+        for i, c in enumerate(cases):
+            kw = dict(dissect_task="uspace_uvit", t_edit=0.4, write_path_root=d)
+            kw.update(c)
+            tv = kw.pop("tval")
+            out = O.uvit_forward(spec, sd, zt["x"], tv, **kw)
+            np.testing.assert_allclose(out, z[f"case{i}"], err_msg=str(c), **TOL)
+        # skipped-edit cases equal the plain forward at that t
+        plain = O.uvit_forward(spec, sd, zt["x"], 0.41, edit_loc=None)
+        np.testing.assert_allclose(z["case7"], plain, **TOL)
+        # mid hook (token-shaped delta)
+        md = os.path.join(d, "mid")
+        os.makedirs(md)
+        np.save(os.path.join(md, "delta_0.20.npy"), z["tok_attr"])
+        base = dict(dissect_task="uspace_uvit", dissect_name="write_attr", t_edit=0.4,
+                    write_path_root=md, edit_loc="mid")
+        np.testing.assert_allclose(
+            O.uvit_forward(spec, sd, zt["x"], 0.2, ith_attr=2, write_scale=1.0, **base), z["mid0"], **TOL)
+        np.testing.assert_allclose(
+            O.uvit_forward(spec, sd, zt["x"], 0.2, ith_attr="1_3", write_scale=-0.5, **base), z["mid1"], **TOL)
+        # read mode: file name and payload
+        rd = os.path.join(d, "rd")
+        O.uvit_forward(spec, sd, zt["x"], 0.37, edit_loc="tail", dissect_task="uspace_uvit",
+                       dissect_name="read", read_path_root=rd, batch_id=5)
+        assert sorted(os.listdir(rd)) == ["5_0.37.npy"]
+        np.testing.assert_allclose(np.load(os.path.join(rd, "5_0.37.npy")), z["read_tail"], **TOL)
+        with pytest.raises(ValueError):
+            O.uvit_forward(spec, sd, zt["x"], 0.2, edit_loc="head", dissect_task="uspace_uvit", dissect_name="bogus")
+
+
+def test_should_edit_table():
+    assert not O.should_edit("0.00", 0.4)
+    assert O.should_edit("0.40", 0.4) and not O.should_edit("0.41", 0.4)
+    assert O.should_edit("0.40", "every_0.2") and not O.should_edit("0.30", "every_0.2")
+    with pytest.raises(ValueError):
+        O.should_edit("0.10", "sometimes")
+    with pytest.raises(ValueError):
+        O.should_edit("0.10", None)
+
+
+def test_p2p_cases(golden_dir):
+    zt, sd = _load(golden_dir, "tiny_t2i.npz")
+    z = np.load(os.path.join(golden_dir, "p2p_t2i.npz"))
+    cases = json.loads(bytes(z["cases_json"]).decode())
+    spec = O.UViTSpec(t2i=True, clip_dim=32, num_clip_token=77, **TINY)
+    ids = [z["ids_a0"], z["ids_a1"], z["ids_a2"]]
+    outs = []
+    for i, c in enumerate(cases):
+        kw = dict(c)
+        tv = kw.pop("tval")
+        kw.pop("ids")
+        kw["target_context_ids"] = ids
+        out = O.uvit_forward(spec, sd, zt["x"], tv, context=zt["ctx"], **kw)
+        np.testing.assert_allclose(out, z[f"case{i}"], err_msg=str(c), **TOL)
+        outs.append(out)
+    # un-edited variants (encode / lp_* / multiplier 1) equal the flash path at the same t
+    plain = O.uvit_forward(spec, sd, zt["x"], 0.3, context=zt["ctx"])
+    for i in (4, 6, 7):
+        np.testing.assert_allclose(outs[i], plain, rtol=1e-4, atol=1e-5)
+    assert np.abs(outs[0] - plain).max() > 1e-4
