@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of U-ViT-L 256^2-latent flow-matching sampling, batch 64 per GPU,
+50 Dormand-Prince steps (BASELINE.json configs[1]; "dopri5-50" of BASELINE.md = 301 network
+evaluations per solve), on N MI355X of one node.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one full latent -> latent solve of a batch of 64 synthetic latents per GPU (weak scaling:
+independent trajectories, no data-path collective; the final latents are all-gathered once per solve).
+Prints ONE JSON line on rank 0.  Extra fields: NFE, the Euler-50 rate, the roofline of the dominant
+kernel (fc1 GEMM) from live HIP events, and the CPU oracle timed on this host (cpu_baseline).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MODELS = {
+    "L_u": dict(name="uvit", embed_dim=1024, depth=20, num_heads=16, num_classes=-1),
+    "L_t": dict(name="uvit_t2i", embed_dim=1024, depth=20, num_heads=16, clip_dim=768, num_clip_token=77),
+    "S_u": dict(name="uvit", embed_dim=512, depth=16, num_heads=8, num_classes=-1),
+    "S_t": dict(name="uvit_t2i", embed_dim=512, depth=16, num_heads=8, clip_dim=768, num_clip_token=77),
+}
+COMMON = dict(img_size=32, patch_size=2, in_chans=4, mlp_ratio=4, qkv_bias=False, mlp_time_embed=False)
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def flops_per_sample(D, depth, L, t2i):
+    nb, ns = depth + 1, depth // 2
+    f = 2 * L * D * D * (12 * nb + 2 * ns) + 4 * L * L * D * nb + 2 * 256 * 16 * D + 2 * L * D * 16 + 2 * 4 * 4 * 9 * 1024
+    if t2i:
+        f += 2 * 77 * 768 * D
+    return f
+
+
+def cpu_baseline(model_key, nfe, budget_s=20.0):
+    """The CPU oracle (oracle/, a port of the reference forward) timed on this host on a bounded sample."""
+    from oracle import _cops
+    from oracle import uvit_oracle as O
+    cfg = MODELS[model_key]
+    t2i = cfg["name"] == "uvit_t2i"
+    spec = O.UViTSpec(img_size=32, patch_size=2, in_chans=4, embed_dim=cfg["embed_dim"], depth=cfg["depth"],
+                      num_heads=cfg["num_heads"], t2i=t2i)
+    rng = np.random.default_rng(1234)
+    D, Hd = spec.D, spec.hidden
+    sd = {"pos_embed": rng.standard_normal((1, spec.L, D), dtype=np.float32) * 0.02,
+          "patch_embed.proj.weight": rng.standard_normal((D, 4, 2, 2), dtype=np.float32) * 0.1,
+          "patch_embed.proj.bias": np.zeros(D, np.float32)}
+    if t2i:
+        sd["context_embed.weight"] = rng.standard_normal((D, 768), dtype=np.float32) * 0.02
+        sd["context_embed.bias"] = np.zeros(D, np.float32)
+    for b in spec.block_names():
+        for n, shp in (("norm1.weight", (D,)), ("norm2.weight", (D,))):
+            sd[f"{b}.{n}"] = np.ones(shp, np.float32)
+        for n in ("norm1.bias", "norm2.bias", "attn.proj.bias", "mlp.fc2.bias"):
+            sd[f"{b}.{n}"] = np.zeros(D, np.float32)
+        sd[f"{b}.mlp.fc1.bias"] = np.zeros(Hd, np.float32)
+        sd[f"{b}.attn.qkv.weight"] = rng.standard_normal((3 * D, D), dtype=np.float32) * 0.02
+        sd[f"{b}.attn.proj.weight"] = rng.standard_normal((D, D), dtype=np.float32) * 0.02
+        sd[f"{b}.mlp.fc1.weight"] = rng.standard_normal((Hd, D), dtype=np.float32) * 0.02
+        sd[f"{b}.mlp.fc2.weight"] = rng.standard_normal((D, Hd), dtype=np.float32) * 0.02
+        if b.startswith("out_blocks"):
+            sd[f"{b}.skip_linear.weight"] = rng.standard_normal((D, 2 * D), dtype=np.float32) * 0.02
+            sd[f"{b}.skip_linear.bias"] = np.zeros(D, np.float32)
+    sd["norm.weight"], sd["norm.bias"] = np.ones(D, np.float32), np.zeros(D, np.float32)
+    sd["decoder_pred.weight"] = rng.standard_normal((16, D), dtype=np.float32) * 0.02
+    sd["decoder_pred.bias"] = np.zeros(16, np.float32)
+    sd["final_layer.weight"] = rng.standard_normal((4, 4, 3, 3), dtype=np.float32) * 0.1
+    sd["final_layer.bias"] = np.zeros(4, np.float32)
+    Bs = 2
+    x = rng.standard_normal((Bs, 4, 32, 32), dtype=np.float32)
+    ctx = rng.standard_normal((Bs, 77, 768), dtype=np.float32) if t2i else None
+    threads = _cops.lib().oracle_num_threads()
+    O.uvit_forward(spec, sd, x[:1], 0.5, context=None if ctx is None else ctx[:1], edit_loc=None)   # warm-up
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        O.uvit_forward(spec, sd, x, 0.5, context=ctx, edit_loc=None)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or reps >= 8:
+            break
+    per_fwd = el / reps
+    return dict(value=Bs / (per_fwd * nfe), unit="images/sec", cores=int(threads), kind="port",
+                sample=f"{reps} fp32 forwards of batch {Bs} of the C/OpenMP oracle port ({per_fwd:.2f} s each), "
+                       f"extrapolated linearly to {nfe} NFE per solve; host {os.cpu_count()} logical CPUs")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="L_u", choices=sorted(MODELS))
+    ap.add_argument("--batch", type=int, default=64, help="latents per GPU")
+    ap.add_argument("--solver", default="dopri5", choices=["dopri5", "euler"])
+    ap.add_argument("--ode-steps", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the auxiliary Euler-50 measurement")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs ROCm devices"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from uspace_amd import _hip
+    from uspace_amd.sampling import gather_batch
+    from uspace_amd.tools.utils_uvit import get_nnet
+
+    cfg = dict(MODELS[args.model])
+    name = cfg.pop("name")
+    t2i = name == "uvit_t2i"
+    torch.manual_seed(1234)                                    # reference init, SURVEY.md §8(d)
+    net = get_nnet(name, **COMMON, **cfg).to(dev).eval()
+    if t2i:
+        from uspace_amd.flow_matching_t2i import CNF
+    else:
+        from uspace_amd.flow_matching import CNF
+    cnf = CNF(net)
+    B = args.batch
+    g = torch.Generator().manual_seed(7 + rank)
+    z = torch.randn(B, 4, 32, 32, generator=g).to(dev)
+    cond = torch.randn(B, 77, 768, generator=g).to(dev) if t2i else None
+
+    def solver_kwargs(kind):
+        sk = dict(solver_fix="euler", solver_fix_step=1.0 / args.ode_steps, solver_adaptive="dopri5",
+                  solver_adaptive_prec=0.01, n_steps=args.ode_steps)
+        sk["solver"] = "adaptive" if kind == "dopri5" else "fixed"
+        return sk
+
+    def solve(kind):
+        kw = dict(dissect_name="bench", edit_loc=None, solver_kwargs=solver_kwargs(kind))
+        out = cnf.decode(z, cond, **kw) if t2i else cnf.decode(z, None, **kw)
+        return gather_batch(out, B * world)                   # the one collective of the sampling path
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            solve(args.solver)
+        # roofline of the dominant kernel: fc1 GEMM (+bias +GELU -> bf16), timed by HIP events on its own stream
+        D, Hd = cfg["embed_dim"], 4 * cfg["embed_dim"]
+        fc1_flags = _hip.EPI_BIAS | _hip.EPI_GELU | _hip.EPI_OUT_BF16
+        if rank == 0:
+            _hip.prof_gemm_begin(fc1_flags, Hd, D, 8192)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = solve(args.solver)
+        fence()
+        dt = time.perf_counter() - t0
+        nfe = cnf.last_stats.nfe
+        fc1_ms, fc1_n = _hip.prof_gemm_end() if rank == 0 else (0.0, 0)
+        assert bool(torch.isfinite(res).all())
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+        extra = {}
+        if not args.no_extra and args.solver == "dopri5":
+            solve("euler")
+            fence()
+            t1 = time.perf_counter()
+            solve("euler")
+            fence()
+            e = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(e, op=dist.ReduceOp.MAX)
+            extra = dict(euler50_images_per_sec=B * world / float(e.item()), euler50_nfe=cnf.last_stats.nfe)
+
+    if rank == 0:
+        L = net.seq_len
+        M = B * L
+        fps = flops_per_sample(D, cfg["depth"], L, t2i)
+        value = B * world * args.steps / dt
+        line = {
+            "metric": "images/sec, U-ViT-L 256 latent FM sampling (50 ODE steps, bs64) @1/2/4/8 GPU",
+            "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.model} (U-ViT D={D} depth={cfg['depth']} L={L}), batch {B}/GPU, "
+                                   f"{args.solver}-{args.ode_steps} fixed steps, seeded random-init weights, "
+                                   f"latent->latent (VAE excluded)",
+                       "global_batch": B * world, "nfe_per_solve": nfe, "parallelism": f"batch-sharded x{world}"},
+            "nfe": nfe,
+            "sample_nfe_per_sec": B * world * nfe * args.steps / dt,
+            "model_tflops_per_gpu": fps * B * nfe * args.steps / dt / 1e12,
+            "mfma_util_whole_solve": fps * B * nfe * args.steps / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+        }
+        line.update(extra)
+        if fc1_n > 0:
+            flops = 2.0 * M * Hd * D
+            avg_s = fc1_ms / fc1_n / 1e3
+            ach = flops / avg_s / 1e12
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "fc1_traffic.json")
+            if os.path.exists(tp):
+                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+            line["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<256,256,2,4,BIAS|GELU|OUT_BF16> (fc1)",
+                                "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
+                                "launches": fc1_n, "avg_us": 1e6 * avg_s, "flops_per_launch": flops}
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                line["cpu_baseline"] = cpu_baseline(args.model, nfe)
+            except Exception as ex:  # the baseline is reported context, never fatal
+                line["cpu_baseline"] = {"error": repr(ex)}
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

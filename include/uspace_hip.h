@@ -1,0 +1,179 @@
+/*
+ * uspace_hip.h -- C-ABI of the MI355X (gfx950) implementation of uspace's flow-matching
+ * sampling hot path: the U-ViT velocity-network forward evaluated at every ODE step.
+ *
+ * The reference (dongzhuoyao/uspace, paths below relative to its root) is pure Python and
+ * has no FFI of its own; this header is the boundary a maintainer binds instead of the
+ * stock PyTorch ops the reference calls (INTEGRATION.md shows the ctypes stub).  Rules:
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless it says host;
+ *   - the caller owns every buffer (weights blob, workspace, inputs, outputs);
+ *   - every function enqueues on the caller's hipStream_t and never synchronises;
+ *   - return 0 on success, a negative USPACE_ERR_* otherwise; nothing throws;
+ *   - no global state (except the optional launch recorder at the end of this header).
+ * bf16 values cross the boundary as raw uint16_t (upper half of an IEEE fp32, RNE).
+ */
+#ifndef USPACE_HIP_H
+#define USPACE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define USPACE_ABI_VERSION 1
+
+#define USPACE_OK 0
+#define USPACE_ERR_ARG (-1)         /* bad pointer / size / unsupported shape */
+#define USPACE_ERR_LAUNCH (-2)      /* hipGetLastError() != hipSuccess after a launch */
+#define USPACE_ERR_WORKSPACE (-3)   /* workspace too small */
+
+typedef void* uspace_stream_t;      /* a hipStream_t */
+
+#define USPACE_API __attribute__((visibility("default")))
+
+USPACE_API int uspace_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Operators.  Each replaces one stock op of the reference's nnet forward.
+ * ------------------------------------------------------------------------------------- */
+
+/* Epilogue flags for uspace_gemm_bf16 (OR them). */
+#define USPACE_EPI_BIAS 1        /* + bias[N]                                   */
+#define USPACE_EPI_GELU 2        /* exact-erf GELU after bias (libs/timm.py:107) */
+#define USPACE_EPI_RESIDUAL 4    /* + resid_in[M,N] (fp32)                      */
+#define USPACE_EPI_OUT_F32 8     /* write out_f32[M,N]                          */
+#define USPACE_EPI_OUT_BF16 16   /* write out_bf16[M,N]                         */
+
+/* nn.Linear on bf16 operands with fp32 accumulation on the MFMA cores:
+ *     acc[M,N] = [A | A2][M,K] . W[N,K]^T
+ * A is [M,K1] (row stride lda), A2 (optional, may be NULL when K1 == K) is [M,K-K1]
+ * (row stride lda2): the two K-slabs of skip_linear(cat([x, skip])) without materialising
+ * the concat (libs/uvit.py:159).  W is nn.Linear's own [out,in] layout (row stride ldw).
+ * K1 and K must be multiples of 64, N a multiple of 4.  resid_in and out_f32 may alias
+ * (x += ...; libs/uvit.py:160-161).  Replaces libs/uvit.py:89,116,159; libs/timm.py:107-110;
+ * libs/uvit_t2i.py:322. */
+USPACE_API int uspace_gemm_bf16(const uint16_t* A, int lda, const uint16_t* A2, int lda2, int K1,
+                     const uint16_t* W, int ldw, int M, int N, int K, int epi_flags,
+                     const float* bias, const float* resid_in, int ld_resid,
+                     float* out_f32, int ld_f32, uint16_t* out_bf16, int ld_bf16,
+                     uspace_stream_t stream);
+
+/* nn.LayerNorm(D, eps) over fp32 rows -> bf16 rows (libs/uvit.py:135,139,160-161). D % 4 == 0. */
+USPACE_API int uspace_layernorm_f32_bf16(const float* x, const float* gamma, const float* beta, uint16_t* y,
+                              int M, int D, float eps, uspace_stream_t stream);
+
+/* Non-causal multi-head attention, head_dim 64, softmax in fp32 (libs/uvit.py:91-96).
+ * qkv [B*L, 3*H*64] bf16 with columns ordered (3, H, 64); out [B*L, H*64] bf16.
+ * key_scale (optional, [B, L] fp32): the post-softmax map is multiplied column-wise by it
+ * before P.V, without renormalisation -- the attention-map edit of
+ * tools/utils_t2i.py:196-224 at libs/uvit_t2i.py:101-105, applied as a row scaling of V. */
+USPACE_API int uspace_attention_bf16(const uint16_t* qkv, const float* key_scale, uint16_t* out,
+                          int B, int L, int H, uspace_stream_t stream);
+
+/* Token assembly (libs/uvit.py:315-327, libs/uvit_t2i.py:309-324): patch-embed conv (k=s=p) +
+ * sinusoidal time token + optional extra tokens + pos_embed, fp32 -> residual stream
+ * tok[B, L, D] fp32 (+ bf16 copy if tok_bf16 != NULL).
+ *   img [B,C,S,S] fp32; t: B timesteps read as t[b*t_stride] (t_stride 0 for the solver's
+ *   stride-0 expand, flow_matching.py:33); extra [B, n_extra, D] fp32 or NULL.
+ *   time_first != 0: order [time, extra..., patches] (T2I); == 0: [extra..., time, patches]
+ *   (class-conditional: label token precedes the time token, libs/uvit.py:322-326). */
+USPACE_API int uspace_embed_tokens(const float* img, const float* t, int t_stride, const float* extra, int n_extra,
+                        int time_first, const float* patch_w, const float* patch_b, const float* pos,
+                        float* tok, uint16_t* tok_bf16, int B, int C, int S, int p, int D,
+                        uspace_stream_t stream);
+
+/* Output head (libs/uvit.py:342-347): LayerNorm -> decoder_pred (D -> p*p*C) on the patch
+ * tokens -> unpatchify "(p1 p2 C)" -> Conv2d(C,C,3,pad=1).  tok [B,L,D] fp32, out [B,C,S,S]
+ * fp32; scratch must hold B*C*S*S floats. */
+USPACE_API int uspace_output_head(const float* tok, int L, int extras, const float* norm_g, const float* norm_b,
+                       const float* dec_w, const float* dec_b, const float* conv_w, const float* conv_b,
+                       float* scratch, float* out, int B, int C, int S, int p, int D, float eps,
+                       uspace_stream_t stream);
+
+/* x[b, i] += scale * delta[i]  (the u-space write hook, libs/dissection.py:157,178; delta is
+ * broadcast over the batch).  Optionally refreshes a bf16 copy of x. */
+USPACE_API int uspace_add_broadcast(float* x, uint16_t* x_bf16, const float* delta, float scale,
+                         int B, long per_sample, uspace_stream_t stream);
+
+/* fp32 -> bf16 (round to nearest even). */
+USPACE_API int uspace_cast_f32_bf16(const float* src, uint16_t* dst, long n, uspace_stream_t stream);
+
+/* ODE state arithmetic (the integrator the reference delegates to torchdiffeq,
+ * flow_matching.py:118,140,163,172): out = y + sum_i coef[i] * k[i], n_k <= 8.
+ * k is a HOST array of device pointers, coef a HOST array.  out may alias y. */
+USPACE_API int uspace_ode_combine(float* out, const float* y, const float* const* k, const float* coef,
+                       int n_k, long n, uspace_stream_t stream);
+
+/* Scaled RMS error norm of an embedded Runge-Kutta step:
+ *   result[0] = sqrt(mean((err / (atol + rtol * max(|y0|, |y1|)))^2)),  err = sum_i coef[i]*k[i].
+ * result is a device float[1]; scratch a device float[>=1024]. */
+USPACE_API int uspace_ode_error_norm(const float* y0, const float* y1, const float* const* k, const float* coef,
+                          int n_k, float rtol, float atol, long n, float* scratch, float* result,
+                          uspace_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Whole forward: nnet(x, timesteps, ...) of libs/uvit.py:306-351 / libs/uvit_t2i.py:308-342.
+ * ------------------------------------------------------------------------------------- */
+typedef struct uspace_uvit_config {
+    int img_size;      /* 32 */
+    int patch_size;    /* 2 */
+    int in_chans;      /* 4 */
+    int embed_dim;     /* D: multiple of 64 */
+    int depth;         /* even; depth/2 in-blocks, 1 mid, depth/2 out-blocks */
+    int num_heads;     /* embed_dim / 64 */
+    int mlp_hidden;    /* 4*D */
+    int n_extra;       /* extra tokens besides the time token: 0, 1 (label) or 77 (CLIP) */
+    int clip_dim;      /* >0: extra tokens = context_embed(context[B,n_extra,clip_dim]); 0: given */
+    int time_first;    /* 1: [time, extra, patches]; 0: [extra, time, patches] */
+} uspace_uvit_config;
+
+/* Number of fp32 parameter tensors in canonical order, and their element counts.
+ * Canonical order (names are the reference state_dict keys, libs/uvit.py:183-291):
+ *   pos_embed, patch_embed.proj.weight, patch_embed.proj.bias,
+ *   [context_embed.weight, context_embed.bias]            (clip_dim > 0)
+ *   for blk in in_blocks.0.., mid_block, out_blocks.0..:
+ *       [skip_linear.weight, skip_linear.bias]             (out_blocks only)
+ *       norm1.weight, norm1.bias, attn.qkv.weight, attn.proj.weight, attn.proj.bias,
+ *       norm2.weight, norm2.bias, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias
+ *   norm.weight, norm.bias, decoder_pred.weight, decoder_pred.bias,
+ *   final_layer.weight, final_layer.bias */
+USPACE_API int uspace_uvit_num_params(const uspace_uvit_config* cfg);
+USPACE_API long uspace_uvit_param_numel(const uspace_uvit_config* cfg, int index);
+
+USPACE_API size_t uspace_uvit_weight_bytes(const uspace_uvit_config* cfg);
+USPACE_API size_t uspace_uvit_workspace_bytes(const uspace_uvit_config* cfg, int B);
+
+/* Repack fp32 parameters (HOST array of DEVICE pointers, canonical order) into the kernel
+ * layout inside `blob` (GEMM weights -> bf16, the rest fp32). */
+USPACE_API int uspace_uvit_pack_weights(const uspace_uvit_config* cfg, const float* const* params, int n_params,
+                             void* blob, size_t blob_bytes, uspace_stream_t stream);
+
+typedef struct uspace_uvit_io {
+    const float* x;          /* [B,C,S,S] fp32 */
+    const float* t;          /* timesteps, element b at t[b*t_stride] */
+    int t_stride;            /* 0 or 1 */
+    const float* context;    /* [B,n_extra,clip_dim] fp32 (clip_dim>0) or extra tokens [B,n_extra,D] or NULL */
+    const float* mid_delta;  /* optional [L,D] fp32: x += mid_scale*mid_delta after mid_block (libs/uvit.py:336) */
+    float mid_scale;
+    float* mid_tap;          /* optional [B,L,D] fp32: copy of the mid_block output (hook "read" mode) */
+    const float* key_scale;  /* optional [depth+1, B, L] fp32 attention-map column factors per block */
+    float* out;              /* [B,C,S,S] fp32 */
+} uspace_uvit_io;
+
+USPACE_API int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* blob, void* workspace,
+                        size_t workspace_bytes, const uspace_uvit_io* io, int B, uspace_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Measurement aid (bench.py): record HIP events, on the launching stream, around every
+ * uspace_gemm_bf16 launch whose (epi_flags, N, K) match, up to max_launches; _end() waits for
+ * the recorded events and returns their summed duration.  Off unless _begin() was called.
+ * ------------------------------------------------------------------------------------- */
+USPACE_API int uspace_prof_gemm_begin(int epi_flags, int N, int K, int max_launches);
+USPACE_API int uspace_prof_gemm_end(double* total_ms, int* n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* USPACE_HIP_H */

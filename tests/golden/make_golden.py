@@ -156,10 +156,10 @@ def make_tiny_u_cond(uvit):
 def make_tiny_t2i(uvit_t2i):
     torch.manual_seed(WEIGHT_SEED + 2)
     cfg = dict(TINY)
-    m = uvit_t2i.UViT(clip_dim=32, num_clip_token=77, **cfg).eval()
+    m = uvit_t2i.UViT(clip_dim=64, num_clip_token=77, **cfg).eval()
     g = torch.Generator().manual_seed(INPUT_SEED)
     x = torch.randn(3, 4, 16, 16, generator=g)
-    ctx = torch.randn(3, 77, 32, generator=g)
+    ctx = torch.randn(3, 77, 64, generator=g)
     out = {f"sd/{k}": v for k, v in sd_numpy(m).items()}
     out.update(x=x.numpy(), ctx=ctx.numpy())
     tvals = [0.0, 0.62]

@@ -1,0 +1,198 @@
+"""Per-kernel parity: every HIP operator, called through the C-ABI, against the CPU oracle on the
+same seeded inputs.  bf16 operands are rounded once on the host so both sides see identical inputs;
+what remains is fp32 accumulation order (and bf16 rounding of bf16 outputs)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import _cops as C
+from tests.util import bf16_round, rel_l2, to_dev
+
+pytestmark = pytest.mark.gpu
+
+BF16_EPS = 2.0 ** -8   # half-ulp relative rounding of a bf16 store
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from uspace_amd import _hip
+    _hip.lib()
+    return _hip
+
+
+def _rand(rng, *shape, scale=1.0):
+    return (rng.standard_normal(shape) * scale).astype(np.float32)
+
+
+@pytest.mark.parametrize("M,N,K", [
+    (300, 64, 64),        # tiny-model shapes, ragged M, N smaller than the tile
+    (771, 192, 128),
+    (1030, 1024, 256),    # 128x128 tiles, ragged last M tile
+    (4100, 4096, 128),    # 256x256 tiles (>= 256 of them), ragged last M tile
+    (16, 256, 64),
+])
+def test_gemm_plain_and_transpose_detecting(hip, M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    A = bf16_round(_rand(rng, M, K))
+    W = bf16_round(_rand(rng, N, K) * 0.1)      # asymmetric random operands catch row/col swaps
+    ref = C.linear(A, W)
+    out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    hip.gemm(to_dev(A, torch.bfloat16), to_dev(W, torch.bfloat16), out_f32=out)
+    got = out.cpu().numpy()
+    assert rel_l2(got, ref) < 1e-5
+    np.testing.assert_allclose(got, ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
+
+
+def test_gemm_identity_weight_reproduces_rows(hip):
+    # W = I (asymmetric A): output must be A itself, bit-exact in fp32
+    rng = np.random.default_rng(0)
+    A = bf16_round(_rand(rng, 130, 64))
+    out = torch.empty(130, 64, dtype=torch.float32, device="cuda")
+    hip.gemm(to_dev(A, torch.bfloat16), to_dev(np.eye(64, dtype=np.float32), torch.bfloat16), out_f32=out)
+    np.testing.assert_array_equal(out.cpu().numpy(), A)
+
+
+@pytest.mark.parametrize("big", [False, True])
+def test_gemm_epilogues(hip, big):
+    rng = np.random.default_rng(5 + big)
+    M, N, K = (4099, 4096, 64) if big else (515, 256, 192)
+    A = bf16_round(_rand(rng, M, K))
+    W = bf16_round(_rand(rng, N, K) * 0.1)
+    b = _rand(rng, N)
+    R = _rand(rng, M, N)
+    dA, dW, db = to_dev(A, torch.bfloat16), to_dev(W, torch.bfloat16), to_dev(b)
+    lin = C.linear(A, W, b)
+    # bias + GELU -> bf16   (fc1)
+    o16 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    hip.gemm(dA, dW, bias=db, gelu=True, out_bf16=o16)
+    ref = C.gelu(lin)
+    err = np.abs(o16.float().cpu().numpy() - ref)
+    assert (err <= BF16_EPS * np.abs(ref) * 1.01 + 1e-4).all()
+    # bias + residual, in place, + bf16 copy   (proj / fc2)
+    x = to_dev(R).clone()
+    xb = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    hip.gemm(dA, dW, bias=db, resid=x, out_f32=x, out_bf16=xb)
+    ref = lin + R
+    got = x.cpu().numpy()
+    assert rel_l2(got, ref) < 1e-5
+    np.testing.assert_array_equal(xb.float().cpu().numpy(), bf16_round(got))
+    # no bias, bf16 only   (qkv)
+    hip.gemm(dA, dW, out_bf16=o16)
+    ref = C.linear(A, W)
+    err = np.abs(o16.float().cpu().numpy() - ref)
+    assert (err <= BF16_EPS * np.abs(ref) * 1.01 + 1e-4).all()
+
+
+def test_gemm_two_k_slabs_equal_concat(hip):
+    # skip_linear(cat([x, skip], -1)) == x @ W[:, :D]^T + skip @ W[:, D:]^T   (libs/uvit.py:159)
+    rng = np.random.default_rng(9)
+    M, D = 517, 128
+    X = bf16_round(_rand(rng, M, D))
+    S = bf16_round(_rand(rng, M, D))
+    W = bf16_round(_rand(rng, D, 2 * D) * 0.1)
+    b = _rand(rng, D)
+    ref = C.linear(np.concatenate([X, S], axis=1), W, b)
+    out = torch.empty(M, D, dtype=torch.float32, device="cuda")
+    hip.gemm(to_dev(X, torch.bfloat16), to_dev(W, torch.bfloat16), A2=to_dev(S, torch.bfloat16), bias=to_dev(b),
+             out_f32=out)
+    assert rel_l2(out.cpu().numpy(), ref) < 1e-5
+
+
+def test_gemm_rejects_bad_shapes(hip):
+    A = torch.zeros(8, 96, dtype=torch.bfloat16, device="cuda")     # K not a multiple of 64
+    W = torch.zeros(64, 96, dtype=torch.bfloat16, device="cuda")
+    out = torch.empty(8, 64, dtype=torch.float32, device="cuda")
+    with pytest.raises(hip.UspaceHipError):
+        hip.gemm(A, W, out_f32=out)
+
+
+@pytest.mark.parametrize("M,D", [(5, 64), (1031, 512), (777, 1024), (9, 2048)])
+def test_layernorm(hip, M, D):
+    rng = np.random.default_rng(D + M)
+    x = _rand(rng, M, D, scale=3.0) + 0.7
+    g = _rand(rng, D) + 1.0
+    b = _rand(rng, D)
+    ref = C.layernorm(x, g, b)
+    got = hip.layernorm(to_dev(x), to_dev(g), to_dev(b)).float().cpu().numpy()
+    err = np.abs(got - ref)
+    assert (err <= BF16_EPS * np.abs(ref) * 1.01 + 2e-5).all(), err.max()
+
+
+@pytest.mark.parametrize("B,L,H", [(2, 65, 1), (2, 142, 2), (3, 257, 2), (2, 258, 1), (2, 334, 3), (1, 1, 1), (1, 17, 1)])
+@pytest.mark.parametrize("scaled", [False, True])
+def test_attention(hip, B, L, H, scaled):
+    rng = np.random.default_rng(B * 1000 + L + H)
+    qkv = bf16_round(_rand(rng, B, L, 3 * H * 64, scale=1.5))
+    ks = None
+    if scaled:
+        ks = np.ones((B, L), np.float32)
+        ks[:, rng.integers(0, L, size=max(1, L // 9))] = 3.0
+        ks[0, 0] = 0.0
+    ref = C.attention(qkv, H, ks)
+    got = hip.attention(to_dev(qkv.reshape(B * L, -1), torch.bfloat16), B, L, H,
+                        key_scale=to_dev(ks) if scaled else None)
+    got = got.float().cpu().numpy().reshape(B, L, H * 64)
+    # P is rounded to bf16 before P.V (and the output is stored in bf16): ~1e-2 relative at worst
+    assert rel_l2(got, ref) < 6e-3, rel_l2(got, ref)
+    np.testing.assert_allclose(got, ref, rtol=2e-2, atol=2e-2 * np.abs(ref).max())
+
+
+def test_attention_spiked_row_softmax_is_stable(hip):
+    # one key dominates one query by a large margin: exp underflow elsewhere must not produce NaN
+    rng = np.random.default_rng(3)
+    B, L, H = 1, 257, 1
+    qkv = bf16_round(_rand(rng, B, L, 192))
+    qkv[0, 5, 0:64] = 30.0
+    qkv[0, 200, 64:128] = 30.0
+    ref = C.attention(qkv, H)
+    got = hip.attention(to_dev(qkv.reshape(L, -1), torch.bfloat16), B, L, H).float().cpu().numpy().reshape(B, L, 64)
+    assert np.isfinite(got).all()
+    assert rel_l2(got, ref) < 6e-3
+
+
+def test_attention_rejects_long_sequences(hip):
+    qkv = torch.zeros(400, 192, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(hip.UspaceHipError):
+        hip.attention(qkv, 1, 400, 1)
+
+
+def test_add_broadcast_and_cast(hip):
+    rng = np.random.default_rng(4)
+    x = _rand(rng, 3, 4, 16, 16)
+    d = _rand(rng, 4, 16, 16)
+    dx = to_dev(x).clone()
+    xb = torch.empty(x.shape, dtype=torch.bfloat16, device="cuda")
+    hip.add_broadcast(dx, to_dev(d).reshape(-1), -1.5, x_bf16=xb)
+    ref = x + d[None] * np.float32(-1.5)
+    np.testing.assert_allclose(dx.cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(xb.float().cpu().numpy(), bf16_round(dx.cpu().numpy()))
+    odd = _rand(rng, 3, 7)       # per-sample size not a multiple of 4 -> scalar tail kernel
+    dodd = to_dev(odd).clone()
+    hip.add_broadcast(dodd, to_dev(odd[0].copy()), 2.0)
+    np.testing.assert_allclose(dodd.cpu().numpy(), odd + 2.0 * odd[0][None], rtol=1e-6, atol=1e-6)
+    v = _rand(rng, 1003)
+    np.testing.assert_array_equal(hip.cast_bf16(to_dev(v)).float().cpu().numpy(), bf16_round(v))
+
+
+def test_ode_state_kernels(hip):
+    rng = np.random.default_rng(8)
+    n = 4 * 4 * 32 * 32 + 3
+    y = _rand(rng, n)
+    ks = [_rand(rng, n) for _ in range(7)]
+    cs = [0.3, -1.2, 0.0, 2.5, 1e-3, -0.7, 0.11]
+    out = torch.empty(n, device="cuda")
+    hip.ode_combine(out, to_dev(y), [to_dev(k) for k in ks], cs)
+    ref = y.copy()
+    for k, c in zip(ks, cs):
+        ref += np.float32(c) * k
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    y1 = _rand(rng, n)
+    scratch = torch.empty(1024, device="cuda")
+    res = torch.empty(1, device="cuda")
+    hip.ode_error_norm(to_dev(y), to_dev(y1), [to_dev(k) for k in ks], cs, 1e-3, 1e-4, scratch, res)
+    err = np.zeros(n, np.float64)
+    for k, c in zip(ks, cs):
+        err += c * k.astype(np.float64)
+    tol = 1e-4 + 1e-3 * np.maximum(np.abs(y), np.abs(y1))
+    want = np.sqrt(np.mean((err / tol) ** 2))
+    assert abs(float(res.item()) - want) / want < 1e-4

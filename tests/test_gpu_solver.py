@@ -1,0 +1,145 @@
+"""ODE driver on the GPU: HIP state kernels + CNF entry points against the numpy oracle solver and the
+committed Euler-20 trajectory of the reference network (BASELINE.json configs[0])."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import odeint_oracle as OO
+from oracle import uvit_oracle as O
+from tests.util import load_sd, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TINY = dict(img_size=16, patch_size=2, in_chans=4, embed_dim=64, depth=2, num_heads=1, mlp_ratio=4,
+            qkv_bias=False, mlp_time_embed=False)
+
+
+def _field_np(t, y):
+    return (-0.8 * y + np.float32(np.sin(3.0 * t)) + 0.3 * np.tanh(y)).astype(np.float32)
+
+
+def _field_torch(t, y):
+    return -0.8 * y + float(np.sin(3.0 * t)) + 0.3 * torch.tanh(y)
+
+
+@pytest.mark.parametrize("method,kw", [
+    ("euler", dict(step_size=0.01)), ("midpoint", dict(step_size=0.02)), ("rk4", dict(step_size=0.05)),
+    ("euler", dict(n_steps=50)), ("dopri5", dict(n_steps=50)), ("dopri5", {}), ("bosh3", {}), ("adaptive_heun", dict(rtol=1e-3, atol=1e-3)),
+])
+@pytest.mark.parametrize("span", [(0.0, 1.0), (1.0, 0.0), (0.0, 0.4)])
+def test_hip_odeint_matches_oracle_solver(method, kw, span):
+    from uspace_amd.odeint import Stats, odeint
+    rng = np.random.default_rng(1)
+    y0 = rng.standard_normal((3, 4, 8, 8)).astype(np.float32)
+    cnt = {}
+    ref = OO.solve(_field_np, y0, span[0], span[1], method=method, counters=cnt, **kw)
+    st = Stats()
+    got = odeint(_field_torch, torch.from_numpy(y0).cuda(), span[0], span[1], method=method, stats=st, **kw)
+    assert rel_l2(got.cpu().numpy(), ref) < 2e-5
+    assert st.nfe == cnt["nfe"]
+    if method == "dopri5" and "n_steps" in kw:
+        assert st.nfe == 301            # "dopri5-50" of BASELINE.md
+    if method == "euler" and "n_steps" in kw:
+        assert st.nfe == 50
+
+
+def _solver_kwargs(**over):
+    sk = dict(solver="fixed", solver_fix="euler", solver_fix_step=0.05, solver_adaptive="dopri5",
+              solver_adaptive_prec=0.01)
+    sk.update(over)
+    return sk
+
+
+def test_cnf_euler20_matches_reference_trajectory(golden_dir):
+    """configs[0]: S-deep16, B=4, 20 Euler steps; end state vs the reference network's own trajectory."""
+    from uspace_amd.flow_matching import CNF
+    from uspace_amd.tools.utils_uvit import get_nnet
+    z = np.load(os.path.join(golden_dir, "euler20_S_u.npz"))
+    torch.manual_seed(1234)
+    net = get_nnet("uvit", img_size=32, patch_size=2, in_chans=4, embed_dim=512, depth=16, num_heads=8, mlp_ratio=4,
+                   qkv_bias=False, mlp_time_embed=False, num_classes=-1).cuda().eval()
+    cnf = CNF(net)
+    x1 = cnf.decode(torch.from_numpy(z["z"]).cuda(), None, dissect_name="none", edit_loc=None,
+                    solver_kwargs=_solver_kwargs(solver_fix_step=0.05))
+    assert cnf.last_stats.nfe == 20
+    r = rel_l2(x1.cpu().numpy(), z["x1"])
+    assert r < 5e-3, r                   # 20-step trajectory gate
+
+
+def test_cnf_modes_on_tiny_net_match_oracle(golden_dir):
+    from uspace_amd.flow_matching import CNF
+    from uspace_amd.tools.utils_uvit import get_nnet
+    z, sd = load_sd(golden_dir, "tiny_u.npz")
+    net = get_nnet("uvit", num_classes=-1, **TINY)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.cuda().eval()
+    cnf = CNF(net)
+    spec = O.UViTSpec(img_size=16, patch_size=2, in_chans=4, embed_dim=64, depth=2, num_heads=1)
+    f_ref = lambda t, y: O.uvit_forward(spec, sd, y, np.float32(t), edit_loc=None)
+    x0 = torch.from_numpy(z["x"]).cuda()
+
+    # with pytest.raises(KeyError): the reference's decode() indexes kwargs["solver_kwargs"]
+    with pytest.raises(KeyError):
+        cnf.decode(x0, None)
+
+    # non-dissection default: adaptive dopri5 rtol=atol=1e-5 (flow_matching.py:77-84)
+    got = cnf.decode(x0, None, edit_loc=None, solver_kwargs=_solver_kwargs(solver="adaptive"))
+    cnt = {}
+    ref = OO.solve(f_ref, z["x"], 0.0, 1.0, method="dopri5", counters=cnt)
+    assert rel_l2(got.cpu().numpy(), ref) < 1e-2
+    assert abs(cnf.last_stats.nfe - cnt["nfe"]) <= 12      # step sequences may differ by a step or two in bf16
+
+    # fixadp: Euler to t_edit, dopri5 after (flow_matching.py:153-180)
+    got = cnf.decode(x0, None, edit_loc=None, dissect_name="none", t_edit=0.4,
+                     solver_kwargs=_solver_kwargs(solver="fixadp", solver_fix_step=0.1))
+    mid = OO.solve(f_ref, z["x"], 0.0, 0.4, method="euler", step_size=0.1)
+    ref = OO.solve(f_ref, mid, 0.4, 1.0, method="dopri5")
+    assert rel_l2(got.cpu().numpy(), ref) < 1e-2
+
+    # encode (1 -> 0, fixed solver) then decode back ~ identity (dissect_lfm.py:171-178 "vis_reversible")
+    kw = dict(edit_loc=None, dissect_name="none", solver_kwargs=_solver_kwargs(solver_fix="rk4", solver_fix_step=0.05))
+    zz = cnf.encode(x0, None, **kw)
+    back = cnf.decode(zz, None, **kw)
+    assert rel_l2(back.cpu().numpy(), z["x"]) < 5e-3
+    ref = OO.solve(f_ref, z["x"], 1.0, 0.0, method="rk4", step_size=0.05)
+    assert rel_l2(zz.cpu().numpy(), ref) < 1e-2
+
+    with pytest.raises(NotImplementedError):
+        cnf.decode(x0, None, edit_loc=None, dissect_name="none", solver_kwargs=_solver_kwargs(solver="magic"))
+    assert CNF.sample_ode is CNF.decode
+
+
+def test_cnf_t2i_sets_direction_and_edits(golden_dir):
+    from uspace_amd.flow_matching_t2i import CNF
+    from uspace_amd.tools.utils_uvit import get_nnet
+    z, sd = load_sd(golden_dir, "tiny_t2i.npz")
+    net = get_nnet("uvit_t2i", clip_dim=64, num_clip_token=77, **TINY)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.cuda().eval()
+    cnf = CNF(net)
+    x0, ctx = torch.from_numpy(z["x"]).cuda(), torch.from_numpy(z["ctx"]).cuda()
+    ids = [np.array([3, 5]), np.array([], dtype=np.int64), np.array([0, 76])]
+    base = dict(dissect_name="p2p", t_edit=0.5, block_id="all", target_context_ids=ids,
+                token_kwargs=dict(token_dissect="p2p_rescale", p2p_multiplier=4.0),
+                solver_kwargs=_solver_kwargs(solver_fix_step=0.1))
+    plain = cnf.decode(x0, ctx, dissect_name="p2p", t_edit=0.5, block_id="all", target_context_ids=ids,
+                       token_kwargs=dict(token_dissect="p2p_rescale", p2p_multiplier=1.0),
+                       solver_kwargs=_solver_kwargs(solver_fix_step=0.1))
+    edited = cnf.decode(x0, ctx, **base)
+    assert cnf.last_stats.nfe == 10
+    assert rel_l2(edited.cpu().numpy(), plain.cpu().numpy()) > 1e-3      # decode edits while t <= t_edit
+    enc_a = cnf.encode(x0, ctx, **base)                                    # encode never edits
+    enc_b = cnf.encode(x0, ctx, dissect_name="p2p", t_edit=0.5, block_id="all", target_context_ids=ids,
+                       token_kwargs=dict(token_dissect="p2p_rescale", p2p_multiplier=1.0),
+                       solver_kwargs=_solver_kwargs(solver_fix_step=0.1))
+    assert torch.equal(enc_a, enc_b)
+    # oracle trajectory with the same edit
+    spec = O.UViTSpec(img_size=16, patch_size=2, in_chans=4, embed_dim=64, depth=2, num_heads=1, t2i=True,
+                      clip_dim=64, num_clip_token=77)
+    okw = dict(base, fm_direction="decode")
+    okw.pop("solver_kwargs")
+    f_ref = lambda t, y: O.uvit_forward(spec, sd, y, np.float32(t), context=z["ctx"], **okw)
+    ref = OO.solve(f_ref, z["x"], 0.0, 1.0, method="euler", step_size=0.1)
+    assert rel_l2(edited.cpu().numpy(), ref) < 1e-2

@@ -1,0 +1,325 @@
+"""CPU-only checks: host-side control logic, the library/ABI surface, seeded init, solver logic."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import odeint_oracle as OO
+from oracle import uvit_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------------------------------- ABI
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "uspace_hip.h")).read()
+    declared = set(re.findall(r"USPACE_API\s+[\w\s\*]+?\b(uspace_\w+)\s*\(", hdr))
+    assert len(declared) >= 16
+    path = os.path.join(ROOT, "uspace_amd", "libuspace_hip.so")
+    assert os.path.exists(path), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(path)
+    for name in declared:
+        assert hasattr(lib, name), name
+    from uspace_amd import _hip
+    assert set(_hip.SIGNATURES) == declared
+    assert _hip.lib().uspace_abi_version() == 1
+
+
+def test_config_queries_without_gpu():
+    from uspace_amd import _hip
+    L = _hip.lib()
+    cfg = _hip.UvitConfig(32, 2, 4, 1024, 20, 16, 4096, 0, 0, 0)
+    n = L.uspace_uvit_num_params(ctypes.byref(cfg))
+    assert n == 3 + 21 * 11 + 10 * 2 + 6
+    total = sum(L.uspace_uvit_param_numel(ctypes.byref(cfg), i) for i in range(n))
+    assert total == 285737124                          # L-uncond parameter count
+    cfg_t = _hip.UvitConfig(32, 2, 4, 1024, 20, 16, 4096, 77, 768, 1)
+    n_t = L.uspace_uvit_num_params(ctypes.byref(cfg_t))
+    assert sum(L.uspace_uvit_param_numel(ctypes.byref(cfg_t), i) for i in range(n_t)) == 286603428
+    assert L.uspace_uvit_weight_bytes(ctypes.byref(cfg)) > 285737124 * 2
+    assert L.uspace_uvit_workspace_bytes(ctypes.byref(cfg), 64) > 64 * 257 * 1024 * 4
+    bad = _hip.UvitConfig(32, 2, 4, 1000, 20, 16, 4096, 0, 0, 0)      # D not a multiple of 64
+    assert L.uspace_uvit_num_params(ctypes.byref(bad)) < 0
+    assert L.uspace_uvit_weight_bytes(ctypes.byref(bad)) == 0
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _dirs, files in os.walk(os.path.join(ROOT, "uspace_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("DESIGN.md §oracle", ""), f"{f} mentions the oracle"
+
+
+def test_forward_on_cpu_fails_loudly():
+    from uspace_amd import _hip
+    from uspace_amd.tools.utils_uvit import get_nnet
+    net = get_nnet("uvit", img_size=16, patch_size=2, in_chans=4, embed_dim=64, depth=2, num_heads=1)
+    with pytest.raises(_hip.UspaceHipError):
+        net(torch.zeros(1, 4, 16, 16), torch.zeros(1), None, edit_loc=None)
+
+
+# ------------------------------------------------------------------------------------------- module surface
+TINY = dict(img_size=16, patch_size=2, in_chans=4, embed_dim=64, depth=2, num_heads=1, mlp_ratio=4,
+            qkv_bias=False, mlp_time_embed=False)
+
+
+@pytest.mark.parametrize("name,seed,fname,extra", [
+    ("uvit", 1234, "tiny_u.npz", dict(num_classes=-1)),
+    ("uvit", 1235, "tiny_u_cond.npz", dict(num_classes=10)),
+    ("uvit_t2i", 1236, "tiny_t2i.npz", dict(clip_dim=64, num_clip_token=77)),
+])
+def test_state_dict_keys_order_and_seeded_init_equal_reference(golden_dir, name, seed, fname, extra):
+    from uspace_amd.tools.utils_uvit import get_nnet
+    z = np.load(os.path.join(golden_dir, fname))
+    torch.manual_seed(seed)
+    net = get_nnet(name, **TINY, **extra)
+    sd = net.state_dict()
+    ref_keys = [k[3:] for k in z.files if k.startswith("sd/")]
+    assert list(sd.keys()) == ref_keys
+    for k in ref_keys:
+        assert tuple(sd[k].shape) == z["sd/" + k].shape
+        np.testing.assert_array_equal(sd[k].numpy(), z["sd/" + k], err_msg=k)
+    assert net.no_weight_decay() == {"pos_embed"}
+    net.load_state_dict({k: torch.from_numpy(z["sd/" + k]) for k in ref_keys}, strict=True)
+
+
+def test_seeded_init_sha_matches_reference_S(golden_dir):
+    import hashlib
+    from uspace_amd.tools.utils_uvit import get_nnet
+    for kind, name, extra in (("u", "uvit", dict(num_classes=-1)), ("t", "uvit_t2i", dict(clip_dim=768, num_clip_token=77))):
+        z = np.load(os.path.join(golden_dir, f"big_S_{kind}.npz"))
+        meta = json.loads(bytes(z["meta_json"]).decode())
+        torch.manual_seed(meta["weight_seed"])
+        net = get_nnet(name, img_size=32, patch_size=2, in_chans=4, embed_dim=512, depth=16, num_heads=8,
+                       mlp_ratio=4, qkv_bias=False, mlp_time_embed=False, use_checkpoint=True, **extra)
+        h = hashlib.sha256()
+        for k, v in net.state_dict().items():
+            h.update(k.encode())
+            h.update(np.ascontiguousarray(v.numpy()).tobytes())
+        assert h.hexdigest() == meta["sha256"]
+
+
+def test_factory_and_unsupported_configs():
+    from uspace_amd.tools.utils_uvit import amortize, get_nnet
+    with pytest.raises(NotImplementedError):
+        get_nnet("resnet")
+    with pytest.raises(NotImplementedError):
+        get_nnet("unet_t2i")
+    with pytest.raises(NotImplementedError):
+        get_nnet("uvit", **dict(TINY, qkv_bias=True))
+    with pytest.raises(NotImplementedError):
+        get_nnet("uvit", **dict(TINY, embed_dim=96, num_heads=2))     # head_dim 48
+    assert amortize(10, 4) == [4, 4, 2] and amortize(8, 4) == [4, 4] and amortize(3, 4) == [3]
+
+
+# ------------------------------------------------------------------------------------------- hook control plane
+def test_should_edit_and_plan_follow_oracle():
+    from uspace_amd.libs import dissection as D
+    for digit in ("0.00", "0.01", "0.20", "0.40", "0.41", "1.00"):
+        for t_edit in (0.4, 0, 1, "every_0.2", "every_0.1"):
+            assert D.should_edit(digit, t_edit) == O.should_edit(digit, t_edit), (digit, t_edit)
+    for bad in ("sometimes", None, [0.4]):
+        with pytest.raises(ValueError):
+            D.should_edit("0.10", bad)
+    tab = np.arange(5 * 6, dtype=np.float32).reshape(5, 6)
+    np.testing.assert_array_equal(D.select_rows(tab, 2), O.select_delta(tab, 2)[0])
+    np.testing.assert_array_equal(D.select_rows(tab, "0_2_4"), O.select_delta(tab, "0_2_4")[0])
+    base = dict(dissect_task="uspace_uvit", t_edit=0.4, write_path_root="/w", write_scale=2.0)
+    p = D.plan_uspace_hook("0.20", dict(base, dissect_name="write_attr", ith_attr="31_39_20"))
+    assert (p.kind, p.path, p.ith, p.scale) == ("write", "/w/delta_0.20.npy", "31_39_20", 2.0)
+    p = D.plan_uspace_hook("0.20", dict(base, dissect_name="write_pca", ith_component=3, pca_n=100))
+    assert (p.path, p.ith) == ("/w/pca100_0.20.npy", 3)
+    assert D.plan_uspace_hook("0.41", dict(base, dissect_name="write_attr", ith_attr=1)) is None
+    assert D.plan_uspace_hook("0.00", dict(base, dissect_name="write_attr", ith_attr=1)) is None
+    assert D.plan_uspace_hook("0.20", dict(base, dissect_task="other", dissect_name="bogus")) is None
+    p = D.plan_uspace_hook("0.37", dict(dissect_task="uspace_uvit", dissect_name="read", read_path_root="/r", batch_id=5))
+    assert (p.kind, p.path) == ("read", "/r/5_0.37")
+    with pytest.raises(ValueError):
+        D.plan_uspace_hook("0.20", dict(base, dissect_name="bogus"))
+
+
+def test_timestep_digit_rounding_cases():
+    from uspace_amd.libs._uvit_core import timestep_digit
+    assert timestep_digit(0.004) == "0.00" and timestep_digit(0.404) == "0.40" and timestep_digit(0.405) == "0.41"
+    assert timestep_digit(np.float32(0.2)) == "0.20" and timestep_digit(1.0) == "1.00"
+
+
+def test_key_scale_table_equals_oracle_on_golden_cases(golden_dir):
+    from uspace_amd.tools import utils_t2i as T
+    z = np.load(os.path.join(golden_dir, "p2p_t2i.npz"))
+    cases = json.loads(bytes(z["cases_json"]).decode())
+    ids = [z["ids_a0"], z["ids_a1"], z["ids_a2"]]
+    nb, B, L = 3, 3, 142
+    for c in cases:
+        kw = dict(c)
+        tv = kw.pop("tval")
+        kw.pop("ids")
+        kw["target_context_ids"] = ids
+        digit = f"{float(np.float32(tv)):.2f}"
+        got = T.key_scale_table(nb, B, L, digit, kw)
+        want = [O.p2p_column_scale(B, L, tv, kw, blk) for blk in range(nb)]
+        if got is None:
+            assert all(w is None or np.all(w == 1.0) for w in want), c
+        else:
+            for blk in range(nb):
+                w = want[blk] if want[blk] is not None else np.ones((B, L), np.float32)
+                np.testing.assert_array_equal(got[blk], w)
+    with pytest.raises(ValueError):
+        T.key_scale_table(nb, B, L, "0.30", dict(dissect_name="read"))
+    with pytest.raises(NotImplementedError):
+        T.key_scale_table(nb, B, L, "0.30", dict(dissect_name="p2p", fm_direction="decode", t_edit=0.5,
+                                                 token_kwargs=dict(token_dissect="p2p_replace", p2p_multiplier=1)))
+    with pytest.raises(ValueError):
+        T.block_selected("some", 1)
+
+
+# ------------------------------------------------------------------------------------------- solver logic on CPU
+class NumpyOps:
+    """Test-local state arithmetic so the product's odeint control flow can run without a GPU."""
+
+    def __init__(self, like=None):
+        pass
+
+    def prepare(self, y):
+        return np.asarray(y, np.float32)
+
+    def combine(self, y, ks, coefs):
+        out = np.asarray(y, np.float32).copy()
+        for k, c in zip(ks, coefs):
+            out += np.float32(c) * k
+        return out
+
+    def scaled_norm(self, y0, y1, ks, coefs, rtol, atol):
+        err = np.zeros_like(y0)
+        for k, c in zip(ks, coefs):
+            err += np.float32(c) * k
+        tol = np.float32(atol) + np.float32(rtol) * np.maximum(np.abs(y0), np.abs(y1))
+        return float(np.sqrt(np.mean(np.square(err / tol), dtype=np.float32)))
+
+
+def _field(t, y):
+    return (-0.8 * y + np.float32(np.sin(3.0 * t)) + 0.3 * np.tanh(y)).astype(np.float32)
+
+
+@pytest.mark.parametrize("method,kw", [
+    ("euler", dict(step_size=0.01)), ("midpoint", dict(step_size=0.02)), ("rk4", dict(step_size=0.05)),
+    ("dopri5", dict(n_steps=50)), ("dopri5", {}), ("bosh3", {}), ("adaptive_heun", dict(rtol=1e-3, atol=1e-3)),
+])
+@pytest.mark.parametrize("span", [(0.0, 1.0), (1.0, 0.0), (0.3, 0.9)])
+def test_product_odeint_control_flow_matches_oracle(method, kw, span):
+    from uspace_amd.odeint import Stats, odeint
+    y0 = np.random.default_rng(2).standard_normal((2, 4, 4, 4)).astype(np.float32)
+    cnt = {}
+    ref = OO.solve(_field, y0, *span, method=method, counters=cnt, **kw)
+    st = Stats()
+    got = odeint(_field, y0, *span, method=method, ops=NumpyOps(), stats=st, **kw)
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-6)
+    assert st.nfe == cnt["nfe"]
+
+
+def test_solvers_converge_at_their_order_and_agree():
+    exact = lambda y0: None
+    f = lambda t, y: (-2.0 * y).astype(np.float32)
+    y0 = np.ones((8,), np.float32)
+    want = np.exp(-2.0)
+    errs = {}
+    for m, p in (("euler", 1), ("midpoint", 2), ("rk4", 4)):
+        e = [abs(float(OO.solve(f, y0, 0.0, 1.0, method=m, n_steps=n)[0]) - want) for n in (8, 16)]
+        errs[m] = e
+        assert 0.7 * 2 ** p < e[0] / e[1] < 1.4 * 2 ** p, (m, e)
+    fine = OO.solve(f, y0, 0.0, 1.0, method="euler", n_steps=1000)
+    adp = OO.solve(f, y0, 0.0, 1.0, method="dopri5")
+    assert abs(float(adp[0]) - want) < 1e-5 and abs(float(fine[0]) - want) < 1e-3
+    assert OO.grid_points(0, 1, 0.01).size == 101 and OO.grid_points(0, 0.4, 0.01).size == 41
+    from uspace_amd.odeint import fixed_grid
+    np.testing.assert_array_equal(np.array(fixed_grid(0, 1, 0.01)), OO.grid_points(0, 1, 0.01))
+    np.testing.assert_array_equal(np.array(fixed_grid(-1, 0, 0.01)), OO.grid_points(-1, 0, 0.01))
+
+
+class _StubNet(torch.nn.Module):
+    """CPU stand-in for nnet used only to exercise CNF's solver-selection logic."""
+
+    def __init__(self):
+        super().__init__()
+        self.calls = []
+
+    def forward(self, x, t, *args, **kwargs):
+        self.calls.append((float(t.reshape(-1)[0]), t.stride(), args, dict(kwargs)))
+        return -x, None
+
+
+class TorchCpuOps(NumpyOps):
+    def prepare(self, y):
+        return y.detach().float()
+
+    def combine(self, y, ks, coefs):
+        out = y.clone()
+        for k, c in zip(ks, coefs):
+            out += float(c) * k
+        return out
+
+    def scaled_norm(self, y0, y1, ks, coefs, rtol, atol):
+        err = sum(float(c) * k for k, c in zip(ks, coefs))
+        tol = atol + rtol * torch.maximum(y0.abs(), y1.abs())
+        return float(torch.sqrt(torch.mean((err / tol) ** 2)))
+
+
+def test_cnf_solver_selection_mirrors_reference():
+    from uspace_amd.flow_matching import CNF
+    from uspace_amd.flow_matching_t2i import CNF as CNFT
+    sk = dict(solver="fixadp", solver_fix="euler", solver_fix_step=0.01, solver_adaptive="dopri5", solver_adaptive_prec=0.01)
+    net = _StubNet()
+    cnf = CNF(net)
+    cnf.state_ops_factory = TorchCpuOps
+    assert cnf.net is net
+    # non-dissection -> dopri5 1e-5 regardless of solver_kwargs (flow_matching.py:77-84)
+    kw = cnf.get_ode_kwargs(solver_kwargs=sk, dissect_name=None)
+    assert kw == dict(method="dopri5", rtol=1e-5, atol=1e-5, adjoint_params=())
+    fx, ad = cnf.get_ode_kwargs(solver_kwargs=sk, dissect_name="write_attr")
+    assert fx["method"] == "euler" and fx["options"] == dict(step_size=0.01) and ad["method"] == "dopri5"
+    assert cnf.get_ode_kwargs(solver_kwargs=dict(sk, solver="fixed"), dissect_name="x")["options"]["step_size"] == 0.01
+    with pytest.raises(NotImplementedError):
+        cnf.get_ode_kwargs(solver_kwargs=dict(sk, solver="zzz"), dissect_name="x")
+    assert cnf.is_dissection_mode(dict(dissect_name="read")) and not cnf.is_dissection_mode(dict(dissect_name=None))
+    with pytest.raises(KeyError):
+        cnf.decode(torch.zeros(2, 4, 4, 4), None)
+    with pytest.raises(NotImplementedError):
+        cnf.training_losses(None, None, 1e-4)
+
+    z = torch.ones(3, 4, 4, 4)
+    out = cnf.decode(z, "LABEL", dissect_name="write_attr", edit_loc=None, t_edit=0.4, solver_kwargs=sk)
+    ts = [c[0] for c in net.calls]
+    assert ts[:41] == pytest.approx([k * 0.01 for k in range(41)][:41], abs=1e-6) or len(ts) > 41
+    assert abs(ts[39] - 0.39) < 1e-6 and abs(ts[40] - 0.4) < 1e-6          # 40 Euler steps then dopri5 from 0.4
+    assert all(c[1] == (0,) for c in net.calls)                            # stride-0 timesteps
+    assert all(c[2] == ("LABEL",) for c in net.calls)                      # y positional (flow_matching.py:34)
+    assert all("_t_host" in c[3] and c[3]["edit_loc"] is None for c in net.calls)
+    torch.testing.assert_close(out, z * float(np.exp(-1.0)), rtol=2e-2, atol=1e-3)
+
+    net.calls.clear()
+    cnf.encode(z, None, dissect_name=None, solver_kwargs=dict(sk, solver_fix_step=0.25))   # encode: always fixed
+    assert [round(c[0], 6) for c in net.calls] == [1.0, 0.75, 0.5, 0.25]
+
+    net.calls.clear()
+    cnft = CNFT(net)
+    cnft.state_ops_factory = TorchCpuOps
+    kw = dict(dissect_name="p2p", solver_kwargs=dict(sk, solver="fixed", solver_fix_step=0.5))
+    cnft.decode(z, "CTX", **kw)
+    assert [c[3]["fm_direction"] for c in net.calls] == ["decode", "decode"]
+    assert all(c[2] == () and c[3]["context"] == "CTX" for c in net.calls)  # context by keyword
+    net.calls.clear()
+    cnft.encode(z, "CTX", **kw)
+    assert [c[3]["fm_direction"] for c in net.calls] == ["encode", "encode"]
+    assert [round(c[0], 6) for c in net.calls] == [1.0, 0.5]
+    # n_steps extension: "dopri5-50" == 301 evaluations, "euler-50" == 50
+    net.calls.clear()
+    cnf.decode(z, None, dissect_name="bench", edit_loc=None, solver_kwargs=dict(sk, solver="adaptive", n_steps=50))
+    assert len(net.calls) == 301 and cnf.last_stats.nfe == 301
+    net.calls.clear()
+    cnf.decode(z, None, dissect_name="bench", edit_loc=None, solver_kwargs=dict(sk, solver="fixed", n_steps=50))
+    assert len(net.calls) == 50

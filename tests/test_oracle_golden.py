@@ -44,7 +44,7 @@ def test_tiny_u_cond_label_token_order(golden_dir):
 
 def test_tiny_t2i_outputs_and_taps(golden_dir):
     z, sd = _load(golden_dir, "tiny_t2i.npz")
-    spec = O.UViTSpec(t2i=True, clip_dim=32, num_clip_token=77, **TINY)
+    spec = O.UViTSpec(t2i=True, clip_dim=64, num_clip_token=77, **TINY)
     assert spec.L == 142
     for i, tv in enumerate(z["tvals"]):
         taps = {}
@@ -107,7 +107,7 @@ def test_p2p_cases(golden_dir):
     zt, sd = _load(golden_dir, "tiny_t2i.npz")
     z = np.load(os.path.join(golden_dir, "p2p_t2i.npz"))
     cases = json.loads(bytes(z["cases_json"]).decode())
-    spec = O.UViTSpec(t2i=True, clip_dim=32, num_clip_token=77, **TINY)
+    spec = O.UViTSpec(t2i=True, clip_dim=64, num_clip_token=77, **TINY)
     ids = [z["ids_a0"], z["ids_a1"], z["ids_a2"]]
     outs = []
     for i, c in enumerate(cases):

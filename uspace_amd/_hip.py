@@ -1,0 +1,189 @@
+"""ctypes binding of libuspace_hip.so (include/uspace_hip.h).
+
+There is NO fallback: if the shared library is missing or an entry point returns an error the
+caller gets an exception.  torch is used only to own device memory and to name the stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libuspace_hip.so")
+
+EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_OUT_BF16 = 1, 2, 4, 8, 16
+
+_ERR = {-1: "USPACE_ERR_ARG", -2: "USPACE_ERR_LAUNCH", -3: "USPACE_ERR_WORKSPACE"}
+
+
+class UspaceHipError(RuntimeError):
+    pass
+
+
+class UvitConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in (
+        "img_size", "patch_size", "in_chans", "embed_dim", "depth", "num_heads", "mlp_hidden",
+        "n_extra", "clip_dim", "time_first")]
+
+
+class UvitIO(ctypes.Structure):
+    _fields_ = [
+        ("x", ctypes.c_void_p), ("t", ctypes.c_void_p), ("t_stride", ctypes.c_int),
+        ("context", ctypes.c_void_p), ("mid_delta", ctypes.c_void_p), ("mid_scale", ctypes.c_float),
+        ("mid_tap", ctypes.c_void_p), ("key_scale", ctypes.c_void_p), ("out", ctypes.c_void_p)]
+
+
+_P, _I, _L, _F, _SZ = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/uspace_hip.h declares
+SIGNATURES = {
+    "uspace_abi_version": (_I, []),
+    "uspace_gemm_bf16": (_I, [_P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I, _P]),
+    "uspace_layernorm_f32_bf16": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
+    "uspace_attention_bf16": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "uspace_embed_tokens": (_I, [_P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "uspace_output_head": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "uspace_add_broadcast": (_I, [_P, _P, _P, _F, _I, _L, _P]),
+    "uspace_cast_f32_bf16": (_I, [_P, _P, _L, _P]),
+    "uspace_ode_combine": (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _L, _P]),
+    "uspace_ode_error_norm": (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _F, _F, _L, _P, _P, _P]),
+    "uspace_uvit_num_params": (_I, [ctypes.POINTER(UvitConfig)]),
+    "uspace_uvit_param_numel": (_L, [ctypes.POINTER(UvitConfig), _I]),
+    "uspace_uvit_weight_bytes": (_SZ, [ctypes.POINTER(UvitConfig)]),
+    "uspace_uvit_workspace_bytes": (_SZ, [ctypes.POINTER(UvitConfig), _I]),
+    "uspace_uvit_pack_weights": (_I, [ctypes.POINTER(UvitConfig), ctypes.POINTER(_P), _I, _P, _SZ, _P]),
+    "uspace_uvit_forward": (_I, [ctypes.POINTER(UvitConfig), _P, _P, _SZ, ctypes.POINTER(UvitIO), _I, _P]),
+    "uspace_prof_gemm_begin": (_I, [_I, _I, _I, _I]),
+    "uspace_prof_gemm_end": (_I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libuspace_hip.so or raise -- the product path has no CPU / eager fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise UspaceHipError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). uspace_amd has no fallback path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        if L.uspace_abi_version() != 1:
+            raise UspaceHipError("libuspace_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise UspaceHipError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def require_device(t, name="tensor"):
+    if not t.is_cuda:
+        raise UspaceHipError(
+            f"{name} lives on {t.device}: uspace_amd runs only on a ROCm device (MI355X); there is no CPU path")
+
+
+# ------------------------------------------------------------------------------------------
+# thin operator wrappers (used by the parity tests and by the solver); tensors are torch CUDA
+# ------------------------------------------------------------------------------------------
+def gemm(A, W, *, A2=None, bias=None, resid=None, gelu=False, out_f32=None, out_bf16=None):
+    """acc = [A|A2] @ W^T with fused epilogue; A/A2/W are torch.bfloat16, returns (out_f32, out_bf16)."""
+    require_device(A, "A")
+    M, K1 = A.shape
+    N, K = W.shape
+    assert A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16
+    flags = 0
+    if bias is not None:
+        flags |= EPI_BIAS
+    if gelu:
+        flags |= EPI_GELU
+    if resid is not None:
+        flags |= EPI_RESIDUAL
+    if out_f32 is not None:
+        flags |= EPI_OUT_F32
+    if out_bf16 is not None:
+        flags |= EPI_OUT_BF16
+    rc = lib().uspace_gemm_bf16(
+        ptr(A), A.stride(0), ptr(A2), A2.stride(0) if A2 is not None else 0, K1, ptr(W), W.stride(0), M, N, K, flags,
+        ptr(bias), ptr(resid), resid.stride(0) if resid is not None else 0,
+        ptr(out_f32), out_f32.stride(0) if out_f32 is not None else 0,
+        ptr(out_bf16), out_bf16.stride(0) if out_bf16 is not None else 0, stream_ptr())
+    check(rc, "uspace_gemm_bf16")
+    return out_f32, out_bf16
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    require_device(x, "x")
+    M, D = x.shape
+    y = torch.empty(M, D, dtype=torch.bfloat16, device=x.device)
+    check(lib().uspace_layernorm_f32_bf16(ptr(x), ptr(gamma), ptr(beta), ptr(y), M, D, eps, stream_ptr()),
+          "uspace_layernorm_f32_bf16")
+    return y
+
+
+def attention(qkv, B, L, H, key_scale=None):
+    require_device(qkv, "qkv")
+    out = torch.empty(B * L, H * 64, dtype=torch.bfloat16, device=qkv.device)
+    check(lib().uspace_attention_bf16(ptr(qkv), ptr(key_scale), ptr(out), B, L, H, stream_ptr()),
+          "uspace_attention_bf16")
+    return out
+
+
+def add_broadcast(x, delta, scale, x_bf16=None):
+    require_device(x, "x")
+    B = x.shape[0]
+    per = x.numel() // B
+    assert delta.numel() == per and delta.dtype == torch.float32 and x.dtype == torch.float32
+    check(lib().uspace_add_broadcast(ptr(x), ptr(x_bf16), ptr(delta), float(scale), B, per, stream_ptr()),
+          "uspace_add_broadcast")
+    return x
+
+
+def cast_bf16(src):
+    require_device(src, "src")
+    dst = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    check(lib().uspace_cast_f32_bf16(ptr(src), ptr(dst), src.numel(), stream_ptr()), "uspace_cast_f32_bf16")
+    return dst
+
+
+def ode_combine(out, y, ks, coefs):
+    require_device(y, "y")
+    n = len(ks)
+    karr = (ctypes.c_void_p * max(n, 1))(*[k.data_ptr() for k in ks])
+    carr = (ctypes.c_float * max(n, 1))(*[float(c) for c in coefs])
+    check(lib().uspace_ode_combine(ptr(out), ptr(y), karr, carr, n, y.numel(), stream_ptr()), "uspace_ode_combine")
+    return out
+
+
+def ode_error_norm(y0, y1, ks, coefs, rtol, atol, scratch, result):
+    n = len(ks)
+    karr = (ctypes.c_void_p * n)(*[k.data_ptr() for k in ks])
+    carr = (ctypes.c_float * n)(*[float(c) for c in coefs])
+    check(lib().uspace_ode_error_norm(ptr(y0), ptr(y1), karr, carr, n, float(rtol), float(atol), y0.numel(),
+                                      ptr(scratch), ptr(result), stream_ptr()), "uspace_ode_error_norm")
+    return result
+
+
+def prof_gemm_begin(epi_flags, N, K, max_launches=8192):
+    check(lib().uspace_prof_gemm_begin(epi_flags, N, K, max_launches), "uspace_prof_gemm_begin")
+
+
+def prof_gemm_end():
+    ms, n = ctypes.c_double(0.0), ctypes.c_int(0)
+    check(lib().uspace_prof_gemm_end(ctypes.byref(ms), ctypes.byref(n)), "uspace_prof_gemm_end")
+    return ms.value, n.value

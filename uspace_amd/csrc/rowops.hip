@@ -1,0 +1,407 @@
+// HBM-bound row / elementwise kernels of the U-ViT forward for gfx950:
+// LayerNorm, token assembly, output head, u-space add, casts and the ODE state arithmetic.
+// All are one-pass over their input with 16-byte accesses per lane (coalesced along rows).
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, row kept in registers (fp32 in, bf16 out). D % 4 == 0, D <= 4096.
+// Algorithmic HBM bytes per row: 4*D read + 2*D written.
+// ------------------------------------------------------------------------------------------
+template <int NV>  // float4 per lane: supports D <= NV*256
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                        int M, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * D;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            v[i] = *(const f32x4*)(xr + c);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        } else {
+            v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            const float a = v[i][0] - mean, b = v[i][1] - mean, cc = v[i][2] - mean, d = v[i][3] - mean;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    bf16_t* yr = y + (size_t)row * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            const f32x4 g = *(const f32x4*)(gamma + c);
+            const f32x4 b = *(const f32x4*)(beta + c);
+            uint2 p;
+            p.x = pack_bf2((v[i][0] - mean) * rstd * g[0] + b[0], (v[i][1] - mean) * rstd * g[1] + b[1]);
+            p.y = pack_bf2((v[i][2] - mean) * rstd * g[2] + b[2], (v[i][3] - mean) * rstd * g[3] + b[3]);
+            *(uint2*)(yr + c) = p;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Token assembly. grid = B*L blocks; each block writes one token row of D floats.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ img, const float* __restrict__ t, int t_stride,
+                                                    const float* __restrict__ extra, int n_extra, int time_first,
+                                                    const float* __restrict__ pw, const float* __restrict__ pb,
+                                                    const float* __restrict__ pos, float* __restrict__ tok,
+                                                    bf16_t* __restrict__ tok_bf16, int C, int S, int p, int D) {
+    const int g = S / p;
+    const int L = 1 + n_extra + g * g;
+    const int b = blockIdx.x / L;
+    const int l = blockIdx.x % L;
+    const int time_pos = time_first ? 0 : n_extra;
+    const int extra_pos = time_first ? 1 : 0;
+    float* out = tok + (size_t)blockIdx.x * D;
+    bf16_t* outb = tok_bf16 ? tok_bf16 + (size_t)blockIdx.x * D : nullptr;
+    const float* posr = pos + (size_t)l * D;
+    if (l == time_pos) {
+        // timestep_embedding (libs/uvit.py:36-43): [cos(t f_k) | sin(t f_k)], f_k = exp(-ln(1e4) k / half)
+        const float tv = t[(size_t)b * t_stride];
+        const int half = D / 2;
+        for (int d = threadIdx.x; d < D; d += blockDim.x) {
+            float v;
+            if (d < 2 * half) {
+                const int k = d < half ? d : d - half;
+                const float f = expf(-9.210340371976184f * (float)k / (float)half);
+                const float a = tv * f;
+                v = d < half ? cosf(a) : sinf(a);
+            } else {
+                v = 0.f;
+            }
+            v += posr[d];
+            out[d] = v;
+            if (outb) outb[d] = f2bf(v);
+        }
+    } else if (l >= extra_pos && l < extra_pos + n_extra && l != time_pos) {
+        const float* src = extra + ((size_t)b * n_extra + (l - extra_pos)) * D;
+        for (int d = threadIdx.x; d < D; d += blockDim.x) {
+            const float v = src[d] + posr[d];
+            out[d] = v;
+            if (outb) outb[d] = f2bf(v);
+        }
+    } else {
+        // PatchEmbed conv k = s = p (libs/uvit.py:171-178): pixels consumed in (c, i, j) order
+        __shared__ float px[64];
+        const int tpatch = l - (1 + n_extra);
+        const int ph = tpatch / g, pwid = tpatch % g;
+        const int npx = C * p * p;
+        if ((int)threadIdx.x < npx) {
+            const int c = threadIdx.x / (p * p), ij = threadIdx.x % (p * p);
+            const int i = ij / p, j = ij % p;
+            px[threadIdx.x] = img[(((size_t)b * C + c) * S + ph * p + i) * S + pwid * p + j];
+        }
+        __syncthreads();
+        for (int d = threadIdx.x; d < D; d += blockDim.x) {
+            const float* w = pw + (size_t)d * npx;
+            float s = pb[d];
+            for (int e = 0; e < npx; ++e) s += w[e] * px[e];
+            s += posr[d];
+            out[d] = s;
+            if (outb) outb[d] = f2bf(s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Output head, stage 1: LayerNorm + decoder_pred (D -> PD <= 16) on patch tokens + unpatchify.
+// One wave per patch token; 4 tokens per block.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_pred_kernel(const float* __restrict__ tok, int L, int extras,
+                                                        const float* __restrict__ ng, const float* __restrict__ nb,
+                                                        const float* __restrict__ dw, const float* __restrict__ db,
+                                                        float* __restrict__ img, int B, int C, int S, int p, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int g = S / p;
+    const int npatch = g * g;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= B * npatch) return;
+    const int b = idx / npatch, tp = idx % npatch;
+    const float* xr = tok + ((size_t)b * L + extras + tp) * D;
+    float s = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 v = *(const f32x4*)(xr + c);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 v = *(const f32x4*)(xr + c);
+        const float a0 = v[0] - mean, a1 = v[1] - mean, a2 = v[2] - mean, a3 = v[3] - mean;
+        q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    const int PD = p * p * C;  // <= 16
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 v = *(const f32x4*)(xr + c);
+        const f32x4 gg = *(const f32x4*)(ng + c);
+        const f32x4 bb = *(const f32x4*)(nb + c);
+        f32x4 n;
+        n[0] = (v[0] - mean) * rstd * gg[0] + bb[0];
+        n[1] = (v[1] - mean) * rstd * gg[1] + bb[1];
+        n[2] = (v[2] - mean) * rstd * gg[2] + bb[2];
+        n[3] = (v[3] - mean) * rstd * gg[3] + bb[3];
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+            if (o < PD) {
+                const f32x4 w = *(const f32x4*)(dw + (size_t)o * D + c);
+                acc[o] += (n[0] * w[0] + n[1] * w[1]) + (n[2] * w[2] + n[3] * w[3]);
+            }
+        }
+    }
+    const int ph = tp / g, pwid = tp % g;
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+        if (o < PD) {
+            const float r = wave_sum(acc[o]) + db[o];
+            if (lane == 0) {
+                // unpatchify "(p1 p2 C)" (libs/uvit.py:60-62)
+                const int c = o % C, p12 = o / C;
+                const int p1 = p12 / p, p2 = p12 % p;
+                img[(((size_t)b * C + c) * S + ph * p + p1) * S + pwid * p + p2] = r;
+            }
+        }
+    }
+}
+
+// Output head, stage 2: Conv2d(C, C, 3, padding=1) (libs/uvit.py:284-288). One thread per output pixel.
+__global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ out,
+                                                      int B, int C, int S) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)B * C * S * S;
+    if (i >= total) return;
+    const int xx = i % S, yy = (i / S) % S, co = (i / ((long)S * S)) % C, b = i / ((long)S * S * C);
+    float s = bias[co];
+    for (int ci = 0; ci < C; ++ci)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int y2 = yy + dy, x2 = xx + dx;
+                if (y2 < 0 || y2 >= S || x2 < 0 || x2 >= S) continue;
+                s += w[((co * C + ci) * 3 + dy + 1) * 3 + dx + 1] * in[(((size_t)b * C + ci) * S + y2) * S + x2];
+            }
+    out[i] = s;
+}
+
+// x[b, i] += scale * delta[i]; optional bf16 copy refresh. per_sample % 4 == 0.
+__global__ __launch_bounds__(256) void add_bcast_kernel(float* __restrict__ x, bf16_t* __restrict__ xb,
+                                                        const float* __restrict__ delta, float scale,
+                                                        long per_sample4, long total4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const long j = i % per_sample4;
+        f32x4 v = ((f32x4*)x)[i];
+        const f32x4 d = ((const f32x4*)delta)[j];
+        v += d * scale;
+        ((f32x4*)x)[i] = v;
+        if (xb) {
+            uint2 p;
+            p.x = pack_bf2(v[0], v[1]);
+            p.y = pack_bf2(v[2], v[3]);
+            ((uint2*)xb)[i] = p;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void add_bcast_tail_kernel(float* x, bf16_t* xb, const float* delta, float scale,
+                                                             long per_sample, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const float v = x[i] + scale * delta[i % per_sample];
+        x[i] = v;
+        if (xb) xb[i] = f2bf(v);
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = ((const f32x4*)src)[i];
+        uint2 p;
+        p.x = pack_bf2(v[0], v[1]);
+        p.y = pack_bf2(v[2], v[3]);
+        ((uint2*)dst)[i] = p;
+    }
+    const long rem0 = n4 << 2;
+    if (blockIdx.x == 0 && threadIdx.x < (n - rem0)) dst[rem0 + threadIdx.x] = f2bf(src[rem0 + threadIdx.x]);
+}
+
+struct KPtrs {
+    const float* k[8];
+    float c[8];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void ode_combine_kernel(float* __restrict__ out, const float* __restrict__ y, KPtrs kp, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = y[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < kp.n) v += kp.c[j] * kp.k[j][i];
+        out[i] = v;
+    }
+}
+
+// partial sums of (err / (atol + rtol*max(|y0|,|y1|)))^2, one per block, then a 1-block finish
+__global__ __launch_bounds__(256) void ode_err_partial_kernel(const float* __restrict__ y0, const float* __restrict__ y1,
+                                                              KPtrs kp, float rtol, float atol, long n,
+                                                              float* __restrict__ partial) {
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float e = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < kp.n) e += kp.c[j] * kp.k[j][i];
+        const float tol = atol + rtol * fmaxf(fabsf(y0[i]), fabsf(y1[i]));
+        const float r = e / tol;
+        s += r * r;
+    }
+    __shared__ float red[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void ode_err_finish_kernel(const float* __restrict__ partial, int nblk, long n,
+                                                             float* __restrict__ result) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) s += partial[i];
+    __shared__ float red[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) result[0] = sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)n);
+}
+
+inline int grid_for(long n_items, int cap = 2048) {
+    long g = (n_items + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int uspace_abi_version(void) { return USPACE_ABI_VERSION; }
+
+extern "C" int uspace_layernorm_f32_bf16(const float* x, const float* gamma, const float* beta, uint16_t* y,
+                                         int M, int D, float eps, uspace_stream_t stream) {
+    if (!x || !gamma || !beta || !y || M <= 0 || D <= 0 || (D & 3) || D > 4096) return USPACE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = us_cdiv(M, 4);
+    if (D <= 256) hipLaunchKernelGGL(layernorm_kernel<1>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, M, D, eps);
+    else if (D <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, M, D, eps);
+    else if (D <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, M, D, eps);
+    else if (D <= 2048) hipLaunchKernelGGL(layernorm_kernel<8>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, M, D, eps);
+    else hipLaunchKernelGGL(layernorm_kernel<16>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, M, D, eps);
+    US_CHECK_LAUNCH();
+    return USPACE_OK;
+}
+
+extern "C" int uspace_embed_tokens(const float* img, const float* t, int t_stride, const float* extra, int n_extra,
+                                   int time_first, const float* patch_w, const float* patch_b, const float* pos,
+                                   float* tok, uint16_t* tok_bf16, int B, int C, int S, int p, int D,
+                                   uspace_stream_t stream) {
+    if (!img || !t || !patch_w || !patch_b || !pos || !tok) return USPACE_ERR_ARG;
+    if (B <= 0 || C <= 0 || S <= 0 || p <= 0 || D <= 0 || S % p || C * p * p > 64 || n_extra < 0) return USPACE_ERR_ARG;
+    if (n_extra > 0 && !extra) return USPACE_ERR_ARG;
+    const int g = S / p;
+    const int L = 1 + n_extra + g * g;
+    hipLaunchKernelGGL(embed_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, img, t, t_stride, extra, n_extra,
+                       time_first, patch_w, patch_b, pos, tok, tok_bf16, C, S, p, D);
+    US_CHECK_LAUNCH();
+    return USPACE_OK;
+}
+
+extern "C" int uspace_output_head(const float* tok, int L, int extras, const float* norm_g, const float* norm_b,
+                                  const float* dec_w, const float* dec_b, const float* conv_w, const float* conv_b,
+                                  float* scratch, float* out, int B, int C, int S, int p, int D, float eps,
+                                  uspace_stream_t stream) {
+    if (!tok || !norm_g || !norm_b || !dec_w || !dec_b || !conv_w || !conv_b || !scratch || !out) return USPACE_ERR_ARG;
+    if (B <= 0 || (D & 3) || S % p || p * p * C > 16) return USPACE_ERR_ARG;
+    const int g = S / p;
+    if (extras + g * g != L) return USPACE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(head_pred_kernel, dim3(us_cdiv(B * g * g, 4)), dim3(256), 0, s, tok, L, extras, norm_g, norm_b,
+                       dec_w, dec_b, scratch, B, C, S, p, D, eps);
+    US_CHECK_LAUNCH();
+    const long total = (long)B * C * S * S;
+    hipLaunchKernelGGL(conv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, scratch, conv_w, conv_b,
+                       out, B, C, S);
+    US_CHECK_LAUNCH();
+    return USPACE_OK;
+}
+
+extern "C" int uspace_add_broadcast(float* x, uint16_t* x_bf16, const float* delta, float scale, int B,
+                                    long per_sample, uspace_stream_t stream) {
+    if (!x || !delta || B <= 0 || per_sample <= 0) return USPACE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * per_sample;
+    if ((per_sample & 3) == 0) {
+        hipLaunchKernelGGL(add_bcast_kernel, dim3(grid_for(total >> 2)), dim3(256), 0, s, x, x_bf16, delta, scale,
+                           per_sample >> 2, total >> 2);
+    } else {
+        hipLaunchKernelGGL(add_bcast_tail_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, x_bf16, delta, scale,
+                           per_sample, total);
+    }
+    US_CHECK_LAUNCH();
+    return USPACE_OK;
+}
+
+extern "C" int uspace_cast_f32_bf16(const float* src, uint16_t* dst, long n, uspace_stream_t stream) {
+    if (!src || !dst || n <= 0) return USPACE_ERR_ARG;
+    if (((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return USPACE_ERR_ARG;
+    hipLaunchKernelGGL(cast_kernel, dim3(grid_for((n >> 2) + 1)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+    US_CHECK_LAUNCH();
+    return USPACE_OK;
+}
+
+extern "C" int uspace_ode_combine(float* out, const float* y, const float* const* k, const float* coef, int n_k,
+                                  long n, uspace_stream_t stream) {
+    if (!out || !y || n <= 0 || n_k < 0 || n_k > 8 || (n_k > 0 && (!k || !coef))) return USPACE_ERR_ARG;
+    KPtrs kp;
+    kp.n = n_k;
+    for (int i = 0; i < 8; ++i) {
+        kp.k[i] = i < n_k ? k[i] : nullptr;
+        kp.c[i] = i < n_k ? coef[i] : 0.f;
+    }
+    hipLaunchKernelGGL(ode_combine_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out, y, kp, n);
+    US_CHECK_LAUNCH();
+    return USPACE_OK;
+}
+
+extern "C" int uspace_ode_error_norm(const float* y0, const float* y1, const float* const* k, const float* coef,
+                                     int n_k, float rtol, float atol, long n, float* scratch, float* result,
+                                     uspace_stream_t stream) {
+    if (!y0 || !y1 || !k || !coef || !scratch || !result || n <= 0 || n_k <= 0 || n_k > 8) return USPACE_ERR_ARG;
+    KPtrs kp;
+    kp.n = n_k;
+    for (int i = 0; i < 8; ++i) {
+        kp.k[i] = i < n_k ? k[i] : nullptr;
+        kp.c[i] = i < n_k ? coef[i] : 0.f;
+    }
+    const int nblk = grid_for(n, 1024);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ode_err_partial_kernel, dim3(nblk), dim3(256), 0, s, y0, y1, kp, rtol, atol, n, scratch);
+    US_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ode_err_finish_kernel, dim3(1), dim3(256), 0, s, scratch, nblk, n, result);
+    US_CHECK_LAUNCH();
+    return USPACE_OK;
+}

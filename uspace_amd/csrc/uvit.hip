@@ -1,0 +1,262 @@
+// Whole-forward orchestration of the U-ViT velocity network on one MI355X:
+//   nnet(x, timesteps, ...) of the reference (libs/uvit.py:306-351, libs/uvit_t2i.py:308-342)
+// as a fixed sequence of gfx950 kernels on the caller's stream.  No allocation, no sync:
+// the caller provides the packed-weights blob and a workspace sized by
+// uspace_uvit_workspace_bytes(); the sequence is hipGraph-capturable.
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+constexpr size_t ALIGN = 256;
+inline size_t align_up(size_t v) { return (v + ALIGN - 1) / ALIGN * ALIGN; }
+
+enum Kind { F32 = 0, BF16 = 1 };
+
+struct ParamDesc {
+    long numel;
+    Kind kind;
+    size_t offset;  // byte offset in the blob
+};
+
+struct Layout {
+    std::vector<ParamDesc> p;
+    size_t bytes = 0;
+    int add(long numel, Kind k) {
+        ParamDesc d{numel, k, bytes};
+        bytes = align_up(bytes + (size_t)numel * (k == BF16 ? 2 : 4));
+        p.push_back(d);
+        return (int)p.size() - 1;
+    }
+};
+
+struct BlockIdx {
+    int skip_w = -1, skip_b = -1;
+    int n1w, n1b, qkv, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b;
+};
+
+struct Model {
+    Layout lay;
+    int pos, pw, pb, cw = -1, cb = -1;
+    std::vector<BlockIdx> blk;
+    int ng, nb, dw, db, convw, convb;
+    int L, extras, npatch, nblocks;
+};
+
+bool valid_cfg(const uspace_uvit_config* c) {
+    if (!c) return false;
+    if (c->img_size <= 0 || c->patch_size <= 0 || c->img_size % c->patch_size) return false;
+    if (c->in_chans <= 0 || c->in_chans * c->patch_size * c->patch_size > 16) return false;
+    if (c->embed_dim <= 0 || c->embed_dim % 64 || c->num_heads * 64 != c->embed_dim) return false;
+    if (c->depth <= 0 || (c->depth & 1)) return false;
+    if (c->mlp_hidden <= 0 || c->mlp_hidden % 64) return false;
+    if (c->n_extra < 0 || c->clip_dim < 0 || (c->clip_dim % 64)) return false;
+    if (c->clip_dim > 0 && c->n_extra == 0) return false;
+    return true;
+}
+
+// Canonical parameter order (documented in include/uspace_hip.h).
+Model build_model(const uspace_uvit_config& c) {
+    Model m;
+    const long D = c.embed_dim, Hd = c.mlp_hidden;
+    const int g = c.img_size / c.patch_size;
+    m.npatch = g * g;
+    m.extras = 1 + c.n_extra;
+    m.L = m.extras + m.npatch;
+    m.pos = m.lay.add((long)m.L * D, F32);
+    m.pw = m.lay.add(D * c.in_chans * c.patch_size * c.patch_size, F32);
+    m.pb = m.lay.add(D, F32);
+    if (c.clip_dim > 0) {
+        m.cw = m.lay.add(D * c.clip_dim, BF16);
+        m.cb = m.lay.add(D, F32);
+    }
+    const int half = c.depth / 2;
+    m.nblocks = c.depth + 1;
+    for (int i = 0; i < m.nblocks; ++i) {
+        BlockIdx b;
+        if (i > half) {
+            b.skip_w = m.lay.add(D * 2 * D, BF16);
+            b.skip_b = m.lay.add(D, F32);
+        }
+        b.n1w = m.lay.add(D, F32);
+        b.n1b = m.lay.add(D, F32);
+        b.qkv = m.lay.add(3 * D * D, BF16);
+        b.projw = m.lay.add(D * D, BF16);
+        b.projb = m.lay.add(D, F32);
+        b.n2w = m.lay.add(D, F32);
+        b.n2b = m.lay.add(D, F32);
+        b.fc1w = m.lay.add(Hd * D, BF16);
+        b.fc1b = m.lay.add(Hd, F32);
+        b.fc2w = m.lay.add(D * Hd, BF16);
+        b.fc2b = m.lay.add(D, F32);
+        m.blk.push_back(b);
+    }
+    m.ng = m.lay.add(D, F32);
+    m.nb = m.lay.add(D, F32);
+    const long PD = (long)c.patch_size * c.patch_size * c.in_chans;
+    m.dw = m.lay.add(PD * D, F32);
+    m.db = m.lay.add(PD, F32);
+    m.convw = m.lay.add((long)c.in_chans * c.in_chans * 9, F32);
+    m.convb = m.lay.add(c.in_chans, F32);
+    return m;
+}
+
+struct Workspace {
+    size_t x, xb, h, qkv, f, skips, ctx_bf, ctx_f32, head, total;
+};
+
+Workspace plan_workspace(const uspace_uvit_config& c, const Model& m, int B) {
+    Workspace w;
+    const size_t M = (size_t)B * m.L, D = c.embed_dim;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
+    w.x = take(M * D * 4);
+    w.xb = take(M * D * 2);
+    w.h = take(M * D * 2);
+    w.qkv = take(M * 3 * D * 2);
+    w.f = take(M * (size_t)c.mlp_hidden * 2);
+    w.skips = take((size_t)(c.depth / 2) * M * D * 2);
+    w.ctx_bf = take(c.clip_dim > 0 ? (size_t)B * c.n_extra * c.clip_dim * 2 : 0);
+    w.ctx_f32 = take(c.clip_dim > 0 ? (size_t)B * c.n_extra * D * 4 : 0);
+    w.head = take((size_t)B * c.in_chans * c.img_size * c.img_size * 4);
+    w.total = off;
+    return w;
+}
+
+#define US_TRY(expr)                  \
+    do {                              \
+        int rc__ = (expr);            \
+        if (rc__ != USPACE_OK) return rc__; \
+    } while (0)
+
+}  // namespace
+
+extern "C" int uspace_uvit_num_params(const uspace_uvit_config* cfg) {
+    if (!valid_cfg(cfg)) return USPACE_ERR_ARG;
+    return (int)build_model(*cfg).lay.p.size();
+}
+
+extern "C" long uspace_uvit_param_numel(const uspace_uvit_config* cfg, int index) {
+    if (!valid_cfg(cfg)) return USPACE_ERR_ARG;
+    const Model m = build_model(*cfg);
+    if (index < 0 || index >= (int)m.lay.p.size()) return USPACE_ERR_ARG;
+    return m.lay.p[index].numel;
+}
+
+extern "C" size_t uspace_uvit_weight_bytes(const uspace_uvit_config* cfg) {
+    if (!valid_cfg(cfg)) return 0;
+    return build_model(*cfg).lay.bytes;
+}
+
+extern "C" size_t uspace_uvit_workspace_bytes(const uspace_uvit_config* cfg, int B) {
+    if (!valid_cfg(cfg) || B <= 0) return 0;
+    const Model m = build_model(*cfg);
+    return plan_workspace(*cfg, m, B).total;
+}
+
+extern "C" int uspace_uvit_pack_weights(const uspace_uvit_config* cfg, const float* const* params, int n_params,
+                                        void* blob, size_t blob_bytes, uspace_stream_t stream) {
+    if (!valid_cfg(cfg) || !params || !blob) return USPACE_ERR_ARG;
+    const Model m = build_model(*cfg);
+    if (n_params != (int)m.lay.p.size()) return USPACE_ERR_ARG;
+    if (blob_bytes < m.lay.bytes) return USPACE_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < n_params; ++i) {
+        const ParamDesc& d = m.lay.p[i];
+        if (!params[i]) return USPACE_ERR_ARG;
+        char* dst = (char*)blob + d.offset;
+        if (d.kind == BF16) {
+            US_TRY(uspace_cast_f32_bf16(params[i], (uint16_t*)dst, d.numel, stream));
+        } else {
+            if (hipMemcpyAsync(dst, params[i], (size_t)d.numel * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
+                return USPACE_ERR_LAUNCH;
+        }
+    }
+    return USPACE_OK;
+}
+
+extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* blob, void* workspace,
+                                   size_t workspace_bytes, const uspace_uvit_io* io, int B, uspace_stream_t stream) {
+    if (!valid_cfg(cfg) || !blob || !workspace || !io || B <= 0) return USPACE_ERR_ARG;
+    if (!io->x || !io->t || !io->out) return USPACE_ERR_ARG;
+    if (cfg->n_extra > 0 && !io->context) return USPACE_ERR_ARG;
+    const uspace_uvit_config& c = *cfg;
+    const Model m = build_model(c);
+    const Workspace w = plan_workspace(c, m, B);
+    if (workspace_bytes < w.total) return USPACE_ERR_WORKSPACE;
+
+    const int D = c.embed_dim, Hd = c.mlp_hidden, L = m.L, H = c.num_heads;
+    const int M = B * L;
+    const char* wb = (const char*)blob;
+    char* ws = (char*)workspace;
+    auto PF = [&](int idx) { return (const float*)(wb + m.lay.p[idx].offset); };
+    auto PH = [&](int idx) { return (const uint16_t*)(wb + m.lay.p[idx].offset); };
+    float* x = (float*)(ws + w.x);
+    uint16_t* xb = (uint16_t*)(ws + w.xb);
+    uint16_t* h = (uint16_t*)(ws + w.h);
+    uint16_t* qkv = (uint16_t*)(ws + w.qkv);
+    uint16_t* f = (uint16_t*)(ws + w.f);
+    uint16_t* skips = (uint16_t*)(ws + w.skips);
+    const size_t MD = (size_t)M * D;
+
+    constexpr int B_ = USPACE_EPI_BIAS, G_ = USPACE_EPI_GELU, R_ = USPACE_EPI_RESIDUAL, F_ = USPACE_EPI_OUT_F32,
+                  H_ = USPACE_EPI_OUT_BF16;
+
+    // ---- tokens: [time | extra | patches] (+pos)  (libs/uvit.py:315-327; libs/uvit_t2i.py:309-324)
+    const float* extra = nullptr;
+    if (c.n_extra > 0) {
+        if (c.clip_dim > 0) {
+            uint16_t* cbf = (uint16_t*)(ws + w.ctx_bf);
+            float* cf = (float*)(ws + w.ctx_f32);
+            const long n = (long)B * c.n_extra * c.clip_dim;
+            US_TRY(uspace_cast_f32_bf16(io->context, cbf, n, stream));
+            US_TRY(uspace_gemm_bf16(cbf, c.clip_dim, nullptr, 0, c.clip_dim, PH(m.cw), c.clip_dim, B * c.n_extra, D,
+                                    c.clip_dim, B_ | F_, PF(m.cb), nullptr, 0, cf, D, nullptr, 0, stream));
+            extra = cf;
+        } else {
+            extra = io->context;
+        }
+    }
+    US_TRY(uspace_embed_tokens(io->x, io->t, io->t_stride, extra, c.n_extra, c.time_first, PF(m.pw), PF(m.pb),
+                               PF(m.pos), x, nullptr, B, c.in_chans, c.img_size, c.patch_size, D, stream));
+
+    const int half = c.depth / 2;
+    for (int i = 0; i < m.nblocks; ++i) {
+        const BlockIdx& b = m.blk[i];
+        const bool is_in = i < half, is_out = i > half, is_last = i == m.nblocks - 1;
+        if (is_out) {
+            // x = skip_linear(cat([x, skip]))  -- two K slabs, skips popped LIFO (libs/uvit.py:159,340)
+            const uint16_t* skip = skips + (size_t)(m.nblocks - 1 - i) * MD;
+            US_TRY(uspace_gemm_bf16(xb, D, skip, D, D, PH(b.skip_w), 2 * D, M, D, 2 * D, B_ | F_, PF(b.skip_b),
+                                    nullptr, 0, x, D, nullptr, 0, stream));
+        }
+        // x += proj(attn(norm1(x)))
+        US_TRY(uspace_layernorm_f32_bf16(x, PF(b.n1w), PF(b.n1b), h, M, D, 1e-5f, stream));
+        US_TRY(uspace_gemm_bf16(h, D, nullptr, 0, D, PH(b.qkv), D, M, 3 * D, D, H_, nullptr, nullptr, 0, nullptr, 0,
+                                qkv, 3 * D, stream));
+        const float* ks = io->key_scale ? io->key_scale + (size_t)i * B * L : nullptr;
+        US_TRY(uspace_attention_bf16(qkv, ks, h, B, L, H, stream));
+        US_TRY(uspace_gemm_bf16(h, D, nullptr, 0, D, PH(b.projw), D, M, D, D, B_ | R_ | F_, PF(b.projb), x, D, x, D,
+                                nullptr, 0, stream));
+        // x += fc2(gelu(fc1(norm2(x))))
+        US_TRY(uspace_layernorm_f32_bf16(x, PF(b.n2w), PF(b.n2b), h, M, D, 1e-5f, stream));
+        US_TRY(uspace_gemm_bf16(h, D, nullptr, 0, D, PH(b.fc1w), D, M, Hd, D, B_ | G_ | H_, PF(b.fc1b), nullptr, 0,
+                                nullptr, 0, f, Hd, stream));
+        // bf16 copy of the block output: the skip (in-blocks) or the next skip_linear's first K slab
+        uint16_t* copy = is_in ? skips + (size_t)i * MD : (is_last ? nullptr : xb);
+        US_TRY(uspace_gemm_bf16(f, Hd, nullptr, 0, Hd, PH(b.fc2w), Hd, M, D, Hd, copy ? (B_ | R_ | F_ | H_) : (B_ | R_ | F_),
+                                PF(b.fc2b), x, D, x, D, copy, D, stream));
+        if (i == half) {
+            if (io->mid_tap) {
+                if (hipMemcpyAsync(io->mid_tap, x, MD * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+                    return USPACE_ERR_LAUNCH;
+            }
+            if (io->mid_delta)  // u-space write hook at the mid block (libs/uvit.py:336, libs/dissection.py:157)
+                US_TRY(uspace_add_broadcast(x, xb, io->mid_delta, io->mid_scale, B, (long)L * D, stream));
+        }
+    }
+    US_TRY(uspace_output_head(x, L, m.extras, PF(m.ng), PF(m.nb), PF(m.dw), PF(m.db), PF(m.convw), PF(m.convb),
+                              (float*)(ws + w.head), io->out, B, c.in_chans, c.img_size, c.patch_size, D, 1e-5f, stream));
+    return USPACE_OK;
+}

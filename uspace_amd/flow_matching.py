@@ -1,0 +1,123 @@
+"""ODE driver for unconditional / class-conditional sampling (reference: flow_matching.py:15-180).
+
+``CNF(net)`` exposes the reference's sampling entry points -- ``decode`` (noise -> data, t: 0 -> 1),
+``encode`` (data -> noise, t: 1 -> 0), ``decode_fixadp`` (fixed steps up to t_edit, adaptive after)
+-- over this package's own integrators (uspace_amd/odeint.py), because the reference's solver is
+the external torchdiffeq.  ``sample_ode`` (the name BASELINE.json uses) aliases ``decode``.
+"""
+import torch
+import torch.nn as nn
+
+from .odeint import Stats, odeint
+
+_RTOL = 1e-5
+_ATOL = 1e-5
+
+
+class CNFBase(nn.Module):
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+        self.last_stats = None        # odeint.Stats of the most recent solve (NFE etc.)
+        self.state_ops_factory = None  # None -> odeint.HipStateOps (the only implementation shipped)
+
+    # ------------------------------------------------------------------ reference surface
+    def is_dissection_mode(self, kwargs):
+        return "dissect_name" in kwargs and kwargs["dissect_name"] is not None
+
+    def get_ode_kwargs(self, **kwargs):
+        """Same selection rule and dict shape as the reference (flow_matching.py:38-85)."""
+        if not self.is_dissection_mode(kwargs):
+            return dict(method="dopri5", rtol=_RTOL, atol=_ATOL, adjoint_params=())
+        sk = kwargs["solver_kwargs"]
+        fixed = dict(method=sk.get("solver_fix"), rtol=_RTOL, atol=_ATOL, adjoint_params=(),
+                     options=dict(step_size=sk.get("solver_fix_step")))
+        adaptive = dict(method=sk.get("solver_adaptive"), rtol=_RTOL, atol=_ATOL, adjoint_params=())
+        if sk["solver"] == "fixed":
+            return fixed
+        if sk["solver"] == "adaptive":
+            return adaptive
+        if sk["solver"] == "fixadp":
+            return fixed, adaptive
+        raise NotImplementedError(f"solver={sk['solver']}")
+
+    def training_losses(self, *args, **kwargs):
+        raise NotImplementedError(
+            "uspace_amd implements the sampling hot path only (forward kernels, no backward); "
+            "train with the reference's PyTorch modules and load the state_dict here")
+
+    # ------------------------------------------------------------------ integration helpers
+    def _velocity(self, t, x, cond, kwargs):
+        raise NotImplementedError
+
+    def forward(self, t, x, *cond_args, **kwargs):
+        raise NotImplementedError
+
+    def _timesteps(self, t, x):
+        """(B,) stride-0 fp32 view of the scalar time, like ``t.expand(B)`` (flow_matching.py:33)."""
+        if torch.is_tensor(t):
+            if t.numel() != 1:
+                return t, None
+            th = float(t.item())
+        else:
+            th = float(t)
+        return torch.full((), th, dtype=torch.float32, device=x.device).expand(x.shape[0]), th
+
+    def _integrate(self, func, y0, t0, t1, ode_kwargs, n_steps=None):
+        stats = self.last_stats if self.last_stats is not None else Stats()
+        opts = ode_kwargs.get("options") or {}
+        ops = self.state_ops_factory(y0) if self.state_ops_factory is not None else None
+        out = odeint(func, y0, float(t0), float(t1), method=ode_kwargs["method"], rtol=ode_kwargs["rtol"],
+                     atol=ode_kwargs["atol"], step_size=opts.get("step_size"), n_steps=n_steps, stats=stats, ops=ops)
+        self.last_stats = stats
+        return out
+
+    def _solve(self, cond, x, t0, t1, kwargs, force_fixed=False):
+        self.last_stats = Stats()
+        func = lambda t, xx: self._velocity(t, xx, cond, kwargs)
+        sk = kwargs["solver_kwargs"]            # KeyError if absent, as in the reference
+        n_steps = sk.get("n_steps") if hasattr(sk, "get") else None
+        if force_fixed:
+            okw = dict(method=sk["solver_fix"], rtol=_RTOL, atol=_ATOL, adjoint_params=(),
+                       options=dict(step_size=sk["solver_fix_step"]))
+            return self._integrate(func, x, t0, t1, okw, n_steps)
+        if sk["solver"] in ("fixed", "adaptive"):
+            return self._integrate(func, x, t0, t1, self.get_ode_kwargs(**kwargs), n_steps)
+        if sk["solver"] == "fixadp":
+            return self._fixadp(func, x, t0, kwargs["t_edit"], t1, kwargs)
+        raise NotImplementedError(f"unknown solver {sk}")
+
+    def _fixadp(self, func, z, t0, t_mid, t1, kwargs):
+        assert 0 <= t_mid <= 1, f"t_mid={t_mid}"
+        fixed_kw, adaptive_kw = self.get_ode_kwargs(**kwargs)
+        mid = self._integrate(func, z, t0, t_mid, fixed_kw)
+        return self._integrate(func, mid, t_mid, t1, adaptive_kw)
+
+
+class CNF(CNFBase):
+    """``CNF(net).decode(z, y, **kwargs)``; the net is called as ``net(x, t, y, **kwargs)``."""
+
+    def forward(self, t, x, y=None, **kwargs):
+        ts, th = self._timesteps(t, x)
+        if th is not None and "_t_host" not in kwargs:
+            kwargs = dict(kwargs, _t_host=th)
+        pred, _aux = self.net(x, ts, y, **kwargs)            # nnet returns (pred, None), flow_matching.py:34
+        return pred
+
+    def _velocity(self, t, x, cond, kwargs):
+        return self.forward(t, x, cond, **kwargs)
+
+    def encode(self, x, y=None, **kwargs):
+        """Data -> noise with the FIXED solver, t: 1 -> 0 (flow_matching.py:102-128)."""
+        return self._solve(y, x, 1.0, 0.0, kwargs, force_fixed=True)
+
+    def decode(self, z, y=None, **kwargs):
+        """Noise -> data, t: 0 -> 1 (flow_matching.py:130-151)."""
+        return self._solve(y, z, 0.0, 1.0, kwargs)
+
+    def decode_fixadp(self, z, y, t_mid, **kwargs):
+        self.last_stats = Stats()
+        func = lambda t, xx: self._velocity(t, xx, y, kwargs)
+        return self._fixadp(func, z, 0.0, t_mid, 1.0, kwargs)
+
+    sample_ode = decode
