@@ -49,7 +49,7 @@ USPACE_API int uspace_abi_version(void);
 /* nn.Linear on bf16 operands with fp32 accumulation on the MFMA cores:
  *     acc[M,N] = [A | A2][M,K] . W[N,K]^T
  * A is [M,K1] (row stride lda), A2 (optional, may be NULL when K1 == K) is [M,K-K1]
- * (row stride lda2): the two K-slabs of skip_linear(cat([x, skip])) without materialising
+ * (row stride lda2, which must equal lda): the two K-slabs of skip_linear(cat([x, skip])) without materialising
  * the concat (libs/uvit.py:159).  W is nn.Linear's own [out,in] layout (row stride ldw).
  * K1 and K must be multiples of 64, N a multiple of 4.  resid_in and out_f32 may alias
  * (x += ...; libs/uvit.py:160-161).  Replaces libs/uvit.py:89,116,159; libs/timm.py:107-110;

@@ -31,6 +31,7 @@ struct GemmArgs {
     int M, N, K, K1;
     int lda, lda2, ldw, ld_resid, ld_f32, ld_bf16;
     int tiles_m, tiles_n;
+    int m_main, xrows;   // XTRA: rows [m_main, M) are spread over the workgroups, xrows (<=16) each
 };
 
 constexpr int BK = 64;           // bf16 elements per K step (128 B per LDS row)
@@ -39,18 +40,33 @@ constexpr int ROW_BYTES = 128;
 // byte offset inside a [rows][64] bf16 LDS tile of 16-B chunk `c` of row `r` (swizzled)
 __device__ __forceinline__ int lds_off(int r, int c) { return r * ROW_BYTES + ((c ^ ((r >> 1) & 7)) << 4); }
 
-template <int BM, int BN, int WM, int WN, int FLAGS>
+// ------------------------------------------------------------------------------------------
+// Kernel.  Per K tile (64 wide) the wave runs 4 phases (k-slice 0/1 x row-half 0/1) of 16 (8)
+// MFMAs each; every phase first issues the LDS fragment reads of the NEXT phase into the
+// alternate register set and its share of the next tiles' LDS-DMA loads, then its own MFMAs, so
+// matrix-pipe time covers LDS and HBM latency inside one wave.  One barrier per K tile (phase 3).
+//
+// XTRA: besides its BM x BN tile every workgroup owns `xrows` (<= 16) rows of the region
+// [m_main, M) -- one more 16-row MFMA tile shared by the waves -- so a row count like
+// 64*257 = 64*256 + 64 costs 1/16 more matrix work instead of a nearly empty extra round of
+// workgroups (wave quantisation: 65 x 4 = 260 tiles on 256 CUs is 2 rounds, 64 x 4 is 1).
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int FLAGS, bool XTRA>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr int TM = BM / WM / 16;            // 16-row activation sub-tiles per wave
     constexpr int TN = BN / WN / 16;            // 16-col weight sub-tiles per wave
+    constexpr int HM = TM / 2;                  // sub-tiles per row-half (one phase)
+    constexpr int XN = TN / WM;                 // extra-strip sub-tiles per wave
     constexpr int ROWS_PER_ISSUE = THREADS / 8; // one glds instruction moves 8 rows per wave
     constexpr int ISSUES_A = BM / ROWS_PER_ISSUE;
     constexpr int ISSUES_W = BN / ROWS_PER_ISSUE;
     constexpr int TILE_A_BYTES = BM * ROW_BYTES;
     constexpr int TILE_W_BYTES = BN * ROW_BYTES;
-    constexpr int STAGE_BYTES = TILE_A_BYTES + TILE_W_BYTES;
+    constexpr int TILE_X_BYTES = XTRA ? 16 * ROW_BYTES : 0;
+    constexpr int STAGE_BYTES = TILE_A_BYTES + TILE_W_BYTES + TILE_X_BYTES;
     static_assert(BM % ROWS_PER_ISSUE == 0 && BN % ROWS_PER_ISSUE == 0, "tile/threads mismatch");
+    static_assert(TM % 2 == 0 && TN % WM == 0 && WM == 2, "wave tile shape");
 
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
 
@@ -73,21 +89,26 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     const int tile_n = tile % g.tiles_n;
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
+    const int m_lim = XTRA ? g.m_main : g.M;     // rows >= m_lim belong to the extra strips
+    const int x0 = g.m_main + tile_m * g.xrows;  // first extra row of this workgroup
 
-    // ---- per-lane staging sources (row clamped into range; invalid rows are never stored)
+    // ---- per-lane staging sources: 32-bit BYTE offsets from wave-uniform bases (row clamped into
+    //      range; invalid rows are never stored).  Both K slabs share the row stride (checked on host).
     const int srow = tid >> 3;                   // row inside one issue
     const int schunk = tid & 7;                  // LDS chunk position of this lane
-    int a_row[ISSUES_A];   // clamped global row and swizzled source chunk (in elements) per issue
-    int a_col[ISSUES_A];
-    int w_off[ISSUES_W];   // 32-bit element offsets: every operand is < 2^31 elements
+    const bf16_t* const gA = g.A;
+    const bf16_t* const gA2 = g.A2;
+    const bf16_t* const gW = g.W;
+    const int K1 = g.K1;
+    uint32_t a_off[ISSUES_A];
+    uint32_t w_off[ISSUES_W];
 #pragma unroll
     for (int i = 0; i < ISSUES_A; ++i) {
         const int r = i * ROWS_PER_ISSUE + srow;
         const int c = schunk ^ ((r >> 1) & 7);
         int m = m0 + r;
-        m = m < g.M ? m : g.M - 1;
-        a_row[i] = m;
-        a_col[i] = c * 8;
+        m = m < m_lim ? m : m_lim - 1;
+        a_off[i] = (uint32_t)(m * g.lda + c * 8) * 2u;
     }
 #pragma unroll
     for (int i = 0; i < ISSUES_W; ++i) {
@@ -95,95 +116,189 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
         const int c = schunk ^ ((r >> 1) & 7);
         int n = n0 + r;
         n = n < g.N ? n : g.N - 1;
-        w_off[i] = n * g.ldw + c * 8;
+        w_off[i] = (uint32_t)(n * g.ldw + c * 8) * 2u;
+    }
+    uint32_t x_off = 0;
+    if constexpr (XTRA) {   // 16-row extra tile: staged by the first two waves (8 rows each)
+        const int r = tid >> 3;                  // 0..15 for tid < 128
+        const int c = schunk ^ ((r >> 1) & 7);
+        int m = x0 + (r < g.xrows ? r : 0);
+        m = m < g.M ? m : g.M - 1;
+        x_off = (uint32_t)(m * g.lda + c * 8) * 2u;
     }
     const int wave_lds_off = wave * 8 * ROW_BYTES;  // this wave's 8 rows inside an issue
 
-    auto stage = [&](int kt, int buf) {
+    auto stage_a = [&](int kt, int buf) {
         const int k0 = kt * BK;
         char* base = smem + buf * STAGE_BYTES;
-        const bool second = k0 >= g.K1;
-        const bf16_t* abase = second ? g.A2 + (k0 - g.K1) : g.A + k0;
-        const int ld = second ? g.lda2 : g.lda;
+        const char* abase = (const char*)(k0 >= K1 ? gA2 + (k0 - K1) : gA + k0);
 #pragma unroll
         for (int i = 0; i < ISSUES_A; ++i) {
-            const bf16_t* src = abase + (a_row[i] * ld + a_col[i]);
-            __builtin_amdgcn_global_load_lds((const US_GLB void*)src,
+            __builtin_amdgcn_global_load_lds((const US_GLB void*)(abase + a_off[i]),
                                              (US_LDS void*)(base + i * ROWS_PER_ISSUE * ROW_BYTES + wave_lds_off),
                                              16, 0, 0);
         }
+        if constexpr (XTRA) {
+            if (wave < 2)
+                __builtin_amdgcn_global_load_lds((const US_GLB void*)(abase + x_off),
+                                                 (US_LDS void*)(base + TILE_A_BYTES + TILE_W_BYTES + wave_lds_off),
+                                                 16, 0, 0);
+        }
+    };
+    auto stage_w = [&](int kt, int buf) {
+        const char* wbase = (const char*)(gW + kt * BK);
+        char* base = smem + buf * STAGE_BYTES + TILE_A_BYTES;
 #pragma unroll
         for (int i = 0; i < ISSUES_W; ++i) {
-            __builtin_amdgcn_global_load_lds((const US_GLB void*)(g.W + k0 + w_off[i]),
-                                             (US_LDS void*)(base + TILE_A_BYTES + i * ROWS_PER_ISSUE * ROW_BYTES + wave_lds_off),
+            __builtin_amdgcn_global_load_lds((const US_GLB void*)(wbase + w_off[i]),
+                                             (US_LDS void*)(base + i * ROWS_PER_ISSUE * ROW_BYTES + wave_lds_off),
                                              16, 0, 0);
         }
     };
 
+    const int fr = lane & 15;   // fragment row (m for activations, n for weights)
+    const int fq = lane >> 4;   // k-quarter: this lane feeds k = 8*fq .. 8*fq+7 of each 32-wide slice
+    // per-lane LDS byte offsets of the fragments (tile-relative); the swizzle depends on row bits 1..3 only
+    const int a_lds = (wm * (BM / WM) + fr) * ROW_BYTES;
+    const int w_lds = TILE_A_BYTES + (wn * (BN / WN) + fr) * ROW_BYTES;
+    const int x_lds = TILE_A_BYTES + TILE_W_BYTES + fr * ROW_BYTES;
+    const int swz = (fr >> 1) & 7;              // rows advance by 16 between sub-tiles: swizzle key is constant
+    const int c_k0 = ((fq) ^ swz) << 4;         // chunk byte offset for k-slice 0
+    const int c_k1 = ((4 + fq) ^ swz) << 4;     // ... k-slice 1
+
     f32x4 acc[TM][TN];
+    f32x4 xacc[XTRA ? XN : 1];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < (XTRA ? XN : 1); ++j) xacc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int fr = lane & 15;   // fragment row (m for activations, n for weights)
-    const int fq = lane >> 4;   // k-quarter: this lane feeds k = 8*fq .. 8*fq+7 of each 32-wide slice
+    bf16x8 af0[HM], af1[HM], wf0[TN], wf1[TN], xf0, xf1;
 
-    const int nk = g.K / BK;
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();  // (drains the LDS-DMA queue: tile kt landed; everyone left buffer (kt+1)&1)
-        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-        const char* sa = smem + (kt & 1) * STAGE_BYTES;
-        const char* sw = sa + TILE_A_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 wf[TN];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int r = wn * (BN / WN) + j * 16 + fr;
-                wf[j] = *(const bf16x8*)(sw + lds_off(r, ks * 4 + fq));
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int r = wm * (BM / WM) + i * 16 + fr;
-                const bf16x8 af = *(const bf16x8*)(sa + lds_off(r, ks * 4 + fq));
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af, acc[i][j], 0, 0, 0);
-            }
-        }
+#define LOAD_A(dst, base, mh, ck)                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < HM; ++i_)                                               \
+        dst[i_] = *(const bf16x8*)((base) + a_lds + ((mh) * HM + i_) * 16 * ROW_BYTES + (ck));
+#define LOAD_W(dst, base, ck)                                                                       \
+    _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_)                                               \
+        dst[j_] = *(const bf16x8*)((base) + w_lds + j_ * 16 * ROW_BYTES + (ck));
+#define LOAD_X(dst, base, ck) dst = *(const bf16x8*)((base) + x_lds + (ck));
+#define MMA(af, wf, mh, ilo, ihi)                                                                   \
+    _Pragma("unroll") for (int i_ = (ilo); i_ < (ihi); ++i_)                                        \
+        _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_)                                           \
+            acc[(mh) * HM + i_][j_] =                                                               \
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j_], af[i_], acc[(mh) * HM + i_][j_], 0, 0, 0);
+#define MMA_X(xf, wf)                                                                               \
+    if constexpr (XTRA) {                                                                           \
+        _Pragma("unroll") for (int j_ = 0; j_ < XN; ++j_)                                           \
+            xacc[j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm ? wf[XN + j_] : wf[j_], xf, xacc[j_], 0, 0, 0); \
     }
 
+    const int nk = g.K / BK;
+    stage_a(0, 0);
+    stage_w(0, 0);
+    if (nk > 1) stage_a(1, 1);
+    __syncthreads();
+    LOAD_A(af0, smem, 0, c_k0)
+    LOAD_W(wf0, smem, c_k0)
+    if constexpr (XTRA) { LOAD_X(xf0, smem, c_k0) }
+
+#define KTILE(kt, MORE, MORE2)                                                                     \
+    {                                                                                              \
+        const char* cur = smem + (kt & 1) * STAGE_BYTES;                                           \
+        MMA(af0, wf0, 0, 0, 1)                                                                     \
+        MMA_X(xf0, wf0)                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (MORE) stage_w(kt + 1, (kt + 1) & 1);                                                   \
+        LOAD_A(af1, cur, 1, c_k0)                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        MMA(af0, wf0, 0, 1, HM)                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        MMA(af1, wf0, 1, 0, 1)                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        LOAD_A(af0, cur, 0, c_k1)                                                                  \
+        LOAD_W(wf1, cur, c_k1)                                                                     \
+        if constexpr (XTRA) { LOAD_X(xf1, cur, c_k1) }                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        MMA(af1, wf0, 1, 1, HM)                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        MMA(af0, wf1, 0, 0, 1)                                                                     \
+        MMA_X(xf1, wf1)                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        LOAD_A(af1, cur, 1, c_k1)                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        MMA(af0, wf1, 0, 1, HM)                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        MMA(af1, wf1, 1, 0, HM / 2)                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (MORE) {                                                                                \
+            __syncthreads(); /* tile kt+1 landed for everyone; buffer kt&1 is free */              \
+            if (MORE2) stage_a(kt + 2, kt & 1);                                                    \
+            const char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;                                 \
+            LOAD_A(af0, nxt, 0, c_k0)                                                              \
+            LOAD_W(wf0, nxt, c_k0)                                                                 \
+            if constexpr (XTRA) { LOAD_X(xf0, nxt, c_k0) }                                         \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        MMA(af1, wf1, 1, HM / 2, HM)                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    }
+    // steady state is branch-free; the last two K tiles are peeled (no further prefetch / barrier)
+    {
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) KTILE(kt, true, true)
+        if (kt + 1 < nk) { KTILE(kt, true, false) ++kt; }
+        KTILE(kt, false, false)
+    }
+#undef KTILE
+#undef LOAD_A
+#undef LOAD_W
+#undef LOAD_X
+#undef MMA
+#undef MMA_X
+
     // ---- epilogue: lane holds, for sub-tile (i,j), row m = ..+fr and columns n = ..+4*fq+{0,1,2,3}
+    auto emit = [&](f32x4 v, int m, int n) {
+        if constexpr (FLAGS & USPACE_EPI_BIAS) {
+            const f32x4 b = *(const f32x4*)(g.bias + n);
+            v += b;
+        }
+        if constexpr (FLAGS & USPACE_EPI_GELU) {
+            v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+        }
+        if constexpr (FLAGS & USPACE_EPI_RESIDUAL) {
+            const f32x4 r = *(const f32x4*)(g.resid + (size_t)m * g.ld_resid + n);
+            v += r;
+        }
+        if constexpr (FLAGS & USPACE_EPI_OUT_F32) {
+            *(f32x4*)(g.out_f32 + (size_t)m * g.ld_f32 + n) = v;
+        }
+        if constexpr (FLAGS & USPACE_EPI_OUT_BF16) {
+            uint2 p;
+            p.x = pack_bf2(v[0], v[1]);
+            p.y = pack_bf2(v[2], v[3]);
+            *(uint2*)(g.out_bf16 + (size_t)m * g.ld_bf16 + n) = p;
+        }
+    };
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * (BM / WM) + i * 16 + fr;
-        if (m >= g.M) continue;
+        if (m >= m_lim) continue;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * (BN / WN) + j * 16 + fq * 4;
             if (n >= g.N) continue;
-            f32x4 v = acc[i][j];
-            if constexpr (FLAGS & USPACE_EPI_BIAS) {
-                const f32x4 b = *(const f32x4*)(g.bias + n);
-                v += b;
-            }
-            if constexpr (FLAGS & USPACE_EPI_GELU) {
-                v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
-            }
-            if constexpr (FLAGS & USPACE_EPI_RESIDUAL) {
-                const f32x4 r = *(const f32x4*)(g.resid + (size_t)m * g.ld_resid + n);
-                v += r;
-            }
-            if constexpr (FLAGS & USPACE_EPI_OUT_F32) {
-                *(f32x4*)(g.out_f32 + (size_t)m * g.ld_f32 + n) = v;
-            }
-            if constexpr (FLAGS & USPACE_EPI_OUT_BF16) {
-                uint2 p;
-                p.x = pack_bf2(v[0], v[1]);
-                p.y = pack_bf2(v[2], v[3]);
-                *(uint2*)(g.out_bf16 + (size_t)m * g.ld_bf16 + n) = p;
+            emit(acc[i][j], m, n);
+        }
+    }
+    if constexpr (XTRA) {
+        const int m = x0 + fr;
+        if (fr < g.xrows && m < g.M) {
+#pragma unroll
+            for (int j = 0; j < XN; ++j) {
+                const int n = n0 + wn * (BN / WN) + (wm * XN + j) * 16 + fq * 4;
+                if (n < g.N) emit(xacc[j], m, n);
             }
         }
     }
@@ -200,14 +315,44 @@ struct Recorder {
 };
 Recorder g_rec;
 
+// Tiling plan: how many BM-row tile rows get their own workgroups, the rest being spread as extra
+// strips.  Cost model: rounds of workgroups over 256 CUs, each round 1/16 longer with strips.
+struct Plan {
+    int tiles_m, m_main, xrows;
+};
+
+inline Plan plan_rows(int M, int BM, int tiles_n, int wg_per_round) {
+    const int full = M / BM;
+    Plan best{us_cdiv(M, BM), 0, 0};
+    best.m_main = M;
+    double best_cost = (double)us_cdiv(best.tiles_m * tiles_n, wg_per_round);
+    for (int tm = full; tm >= 1 && tm >= full - 8; --tm) {
+        const int rem = M - tm * BM;
+        if (rem <= 0) continue;
+        const int xr = us_cdiv(rem, tm);
+        if (xr > 16) break;
+        const double cost = (double)us_cdiv(tm * tiles_n, wg_per_round) * (1.0 + 1.0 / 16.0);
+        if (cost < best_cost - 1e-9) {
+            best_cost = cost;
+            best = Plan{tm, tm * BM, xr};
+        }
+    }
+    return best;
+}
+
 template <int BM, int BN, int WM, int WN, int FLAGS>
-int launch(const GemmArgs& a, hipStream_t s) {
+int launch(const GemmArgs& a, hipStream_t s, int wg_per_round) {
     GemmArgs g = a;
-    g.tiles_m = us_cdiv(g.M, BM);
     g.tiles_n = us_cdiv(g.N, BN);
+    const Plan p = plan_rows(g.M, BM, g.tiles_n, wg_per_round);
+    g.tiles_m = p.tiles_m;
+    g.m_main = p.m_main;
+    g.xrows = p.xrows;
     const bool rec = g_rec.on && g_rec.flags == FLAGS && g_rec.N == g.N && g_rec.K == g.K && g_rec.used + 2 <= g_rec.cap;
     if (rec) (void)hipEventRecord(g_rec.ev[g_rec.used], s);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, FLAGS>), dim3(g.tiles_m * g.tiles_n), dim3(64 * WM * WN), 0, s, g);
+    const dim3 grid(g.tiles_m * g.tiles_n), block(64 * WM * WN);
+    if (p.xrows > 0) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, FLAGS, true>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, FLAGS, false>), grid, block, 0, s, g);
     if (rec) {
         (void)hipEventRecord(g_rec.ev[g_rec.used + 1], s);
         g_rec.used += 2;
@@ -218,11 +363,11 @@ int launch(const GemmArgs& a, hipStream_t s) {
 
 template <int FLAGS>
 int dispatch_tile(const GemmArgs& a, hipStream_t s) {
-    // 256x256 tiles (8 waves, 128 KiB LDS, 1 workgroup/CU) when they fill the 256 CUs at least
-    // once; otherwise 128x128 tiles (4 waves, 64 KiB LDS, 2 workgroups/CU).
-    const long big_tiles = (long)us_cdiv(a.M, 256) * us_cdiv(a.N, 256);
-    if (big_tiles >= 256) return launch<256, 256, 2, 4, FLAGS>(a, s);
-    return launch<128, 128, 2, 2, FLAGS>(a, s);
+    // 256x256 tiles (8 waves, ~130 KiB LDS, 1 workgroup/CU) when they fill the 256 CUs at least
+    // once; otherwise 128x128 tiles (4 waves, ~66 KiB LDS, 2 workgroups/CU).
+    const long big_tiles = (long)(a.M / 256) * us_cdiv(a.N, 256);
+    if (big_tiles >= 256) return launch<256, 256, 2, 4, FLAGS>(a, s, 256);
+    return launch<128, 128, 2, 2, FLAGS>(a, s, 512);
 }
 
 }  // namespace
@@ -235,7 +380,8 @@ extern "C" int uspace_gemm_bf16(const uint16_t* A, int lda, const uint16_t* A2, 
     if (!A || !W || M <= 0 || N <= 0 || K <= 0) return USPACE_ERR_ARG;
     if (K % BK || K1 % BK || K1 <= 0 || K1 > K || (N & 3)) return USPACE_ERR_ARG;
     if (K1 < K && !A2) return USPACE_ERR_ARG;
-    if ((lda & 7) || (ldw & 7) || (A2 && (lda2 & 7))) return USPACE_ERR_ARG;
+    if ((lda & 7) || (ldw & 7) || (K1 < K && lda2 != lda)) return USPACE_ERR_ARG;
+    if ((long)M * lda >= (1L << 30) || (long)N * ldw >= (1L << 30)) return USPACE_ERR_ARG;   // 32-bit byte offsets
     if ((epi_flags & USPACE_EPI_BIAS) && !bias) return USPACE_ERR_ARG;
     if ((epi_flags & USPACE_EPI_RESIDUAL) && (!resid_in || (ld_resid & 3))) return USPACE_ERR_ARG;
     if ((epi_flags & USPACE_EPI_OUT_F32) && (!out_f32 || (ld_f32 & 3))) return USPACE_ERR_ARG;
@@ -247,6 +393,7 @@ extern "C" int uspace_gemm_bf16(const uint16_t* A, int lda, const uint16_t* A2, 
     g.M = M; g.N = N; g.K = K; g.K1 = K1;
     g.lda = lda; g.lda2 = lda2; g.ldw = ldw; g.ld_resid = ld_resid; g.ld_f32 = ld_f32; g.ld_bf16 = ld_bf16;
     g.tiles_m = g.tiles_n = 0;
+    g.m_main = M; g.xrows = 0;
     hipStream_t s = (hipStream_t)stream;
     constexpr int B_ = USPACE_EPI_BIAS, G_ = USPACE_EPI_GELU, R_ = USPACE_EPI_RESIDUAL,
                   F_ = USPACE_EPI_OUT_F32, H_ = USPACE_EPI_OUT_BF16;
