@@ -16,15 +16,15 @@ typedef uint16_t bf16_t;  // raw storage type used in the C-ABI (no torch / hip_
 #define US_GLB __attribute__((address_space(1)))
 
 // round-to-nearest-even fp32 -> bf16 (NaN kept quiet); matches torch's .to(bfloat16)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// two fp32 -> packed bf16x2 with the hardware converter (v_cvt_pk_bf16_f32, RNE): one instruction
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    bf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -37,6 +37,24 @@ struct GemmArgs {
 constexpr int BK = 64;           // bf16 elements per K step (128 B per LDS row)
 constexpr int ROW_BYTES = 128;
 
+// wave row `wm` owns extra-strip sub-tiles [wm*XN, wm*XN+XN) of its TN weight fragments (select chain:
+// a dynamic register-array index would go to scratch)
+template <int WM, int XN, int TN>
+__device__ __forceinline__ bf16x8 pick_w(const bf16x8 (&wf)[TN], int wm, int j) {
+    bf16x8 r = wf[j];
+#pragma unroll
+    for (int w = 1; w < WM; ++w) r = (wm == w) ? wf[w * XN + j] : r;
+    return r;
+}
+
+template <int WM, int XN, int TN>
+__device__ __forceinline__ f32x4 pick_b(const f32x4 (&b)[TN], int wm, int j) {
+    f32x4 r = b[j];
+#pragma unroll
+    for (int w = 1; w < WM; ++w) r = (wm == w) ? b[w * XN + j] : r;
+    return r;
+}
+
 // byte offset inside a [rows][64] bf16 LDS tile of 16-B chunk `c` of row `r` (swizzled)
 __device__ __forceinline__ int lds_off(int r, int c) { return r * ROW_BYTES + ((c ^ ((r >> 1) & 7)) << 4); }
 
@@ -66,7 +84,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     constexpr int TILE_X_BYTES = XTRA ? 16 * ROW_BYTES : 0;
     constexpr int STAGE_BYTES = TILE_A_BYTES + TILE_W_BYTES + TILE_X_BYTES;
     static_assert(BM % ROWS_PER_ISSUE == 0 && BN % ROWS_PER_ISSUE == 0, "tile/threads mismatch");
-    static_assert(TM % 2 == 0 && TN % WM == 0 && WM == 2, "wave tile shape");
+    static_assert(TM % 2 == 0 && TN % WM == 0 && (WM == 2 || WM == 4), "wave tile shape");
 
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
 
@@ -192,7 +210,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
 #define MMA_X(xf, wf)                                                                               \
     if constexpr (XTRA) {                                                                           \
         _Pragma("unroll") for (int j_ = 0; j_ < XN; ++j_)                                           \
-            xacc[j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm ? wf[XN + j_] : wf[j_], xf, xacc[j_], 0, 0, 0); \
+            xacc[j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pick_w<WM, XN>(wf, wm, j_), xf, xacc[j_], 0, 0, 0); \
     }
 
     const int nk = g.K / BK;
@@ -259,11 +277,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
 #undef MMA_X
 
     // ---- epilogue: lane holds, for sub-tile (i,j), row m = ..+fr and columns n = ..+4*fq+{0,1,2,3}
-    auto emit = [&](f32x4 v, int m, int n) {
-        if constexpr (FLAGS & USPACE_EPI_BIAS) {
-            const f32x4 b = *(const f32x4*)(g.bias + n);
-            v += b;
+    f32x4 bias4[TN];
+    if constexpr (FLAGS & USPACE_EPI_BIAS) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            int n = n0 + wn * (BN / WN) + j * 16 + fq * 4;
+            n = n < g.N ? n : g.N - 4;
+            bias4[j] = *(const f32x4*)(g.bias + n);
         }
+    }
+    auto emit = [&](f32x4 v, const f32x4& b, int m, int n) {
+        if constexpr (FLAGS & USPACE_EPI_BIAS) v += b;
         if constexpr (FLAGS & USPACE_EPI_GELU) {
             v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
         }
@@ -281,15 +305,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
             *(uint2*)(g.out_bf16 + (size_t)m * g.ld_bf16 + n) = p;
         }
     };
+    const bool interior = (m0 + BM <= m_lim) && (n0 + BN <= g.N);   // workgroup-uniform
+    if (interior) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * (BM / WM) + i * 16 + fr;
-        if (m >= m_lim) continue;
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * (BM / WM) + i * 16 + fr;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (BN / WN) + j * 16 + fq * 4;
-            if (n >= g.N) continue;
-            emit(acc[i][j], m, n);
+            for (int j = 0; j < TN; ++j) emit(acc[i][j], bias4[j], m, n0 + wn * (BN / WN) + j * 16 + fq * 4);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * (BM / WM) + i * 16 + fr;
+            if (m >= m_lim) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * (BN / WN) + j * 16 + fq * 4;
+                if (n >= g.N) continue;
+                emit(acc[i][j], bias4[j], m, n);
+            }
         }
     }
     if constexpr (XTRA) {
@@ -298,7 +332,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < XN; ++j) {
                 const int n = n0 + wn * (BN / WN) + (wm * XN + j) * 16 + fq * 4;
-                if (n < g.N) emit(xacc[j], m, n);
+                if (n < g.N) emit(xacc[j], pick_b<WM, XN>(bias4, wm, j), m, n);
             }
         }
     }
