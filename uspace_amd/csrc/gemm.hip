@@ -94,17 +94,29 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     const int wm = wave / WN;
     const int wn = wave % WN;
 
-    // ---- XCD-aware tile id: block b runs on XCD b%8; give each XCD a contiguous tile range
+    // ---- XCD-aware tile id.  Block b runs on XCD b%8 (observed; speed only).  When the grid splits into
+    //      super-tiles of 8 x 4 tiles (one round of an XCD's 32 CUs) each XCD walks whole super-tiles, so
+    //      its 32 resident workgroups share 8 A panels + 4 W panels in its private L2 (12 panel streams
+    //      instead of 18 for a 2 x 16 strip) and keeps its A row-block across rounds.
     const int nwg = g.tiles_m * g.tiles_n;
-    int tile;
+    int tile_m, tile_n;
     {
         const int b = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7;
         const int xcd = b & 7, idx = b >> 3;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int n_super = nwg >> 5;
+        if ((g.tiles_m & 7) == 0 && (g.tiles_n & 3) == 0 && (n_super & 7) == 0) {
+            const int mb_count = g.tiles_m >> 3;
+            const int sup = xcd + 8 * (idx >> 5);
+            const int t = idx & 31;
+            tile_m = (sup % mb_count) * 8 + (t >> 2);
+            tile_n = (sup / mb_count) * 4 + (t & 3);
+        } else {
+            const int q = nwg >> 3, r = nwg & 7;
+            const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+            tile_m = tile / g.tiles_n;
+            tile_n = tile % g.tiles_n;
+        }
     }
-    const int tile_m = tile / g.tiles_n;
-    const int tile_n = tile % g.tiles_n;
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
     const int m_lim = XTRA ? g.m_main : g.M;     // rows >= m_lim belong to the extra strips
