@@ -18,6 +18,10 @@
 
 #include "common.h"
 
+#ifndef GEMM_PRIO
+#define GEMM_PRIO 0
+#endif
+
 namespace {
 
 struct GemmArgs {
@@ -198,12 +202,39 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
 
     f32x4 acc[TM][TN];
     f32x4 xacc[XTRA ? XN : 1];
+    if constexpr (FLAGS & USPACE_EPI_RESIDUAL) {
+        // x += ... : the residual IS the accumulator's initial value.  Its fp32 read (the HBM-bound part of
+        // the proj / fc2 epilogue) is issued here and lands while the first K tiles stream in.
+        // Rows / columns outside the problem are clamped (their accumulators are never stored).
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+            int m = m0 + wm * (BM / WM) + i * 16 + fr;
+            m = m < m_lim ? m : m_lim - 1;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < TN; ++j) {
+                int n = n0 + wn * (BN / WN) + j * 16 + fq * 4;
+                n = n < g.N ? n : g.N - 4;
+                acc[i][j] = *(const f32x4*)(g.resid + (size_t)m * g.ld_resid + n);
+            }
+        }
+        if constexpr (XTRA) {
+            int m = x0 + (fr < g.xrows ? fr : 0);
+            m = m < g.M ? m : g.M - 1;
 #pragma unroll
-    for (int j = 0; j < (XTRA ? XN : 1); ++j) xacc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < XN; ++j) {
+                int n = n0 + wn * (BN / WN) + (wm * XN + j) * 16 + fq * 4;
+                n = n < g.N ? n : g.N - 4;
+                xacc[j] = *(const f32x4*)(g.resid + (size_t)m * g.ld_resid + n);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < (XTRA ? XN : 1); ++j) xacc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
     bf16x8 af0[HM], af1[HM], wf0[TN], wf1[TN], xf0, xf1;
 
@@ -225,6 +256,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
             xacc[j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pick_w<WM, XN>(wf, wm, j_), xf, xacc[j_], 0, 0, 0); \
     }
 
+#if GEMM_PRIO == 1
+    if (wm == 1) __builtin_amdgcn_s_setprio(1);
+#elif GEMM_PRIO == 3
+    if (wm == 1) __builtin_amdgcn_s_setprio(3);
+#endif
     const int nk = g.K / BK;
     stage_a(0, 0);
     stage_w(0, 0);
@@ -302,10 +338,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
         if constexpr (FLAGS & USPACE_EPI_BIAS) v += b;
         if constexpr (FLAGS & USPACE_EPI_GELU) {
             v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
-        }
-        if constexpr (FLAGS & USPACE_EPI_RESIDUAL) {
-            const f32x4 r = *(const f32x4*)(g.resid + (size_t)m * g.ld_resid + n);
-            v += r;
         }
         if constexpr (FLAGS & USPACE_EPI_OUT_F32) {
             *(f32x4*)(g.out_f32 + (size_t)m * g.ld_f32 + n) = v;
