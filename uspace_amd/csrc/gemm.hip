@@ -18,10 +18,6 @@
 
 #include "common.h"
 
-#ifndef GEMM_PRIO
-#define GEMM_PRIO 0
-#endif
-
 namespace {
 
 struct GemmArgs {
@@ -256,11 +252,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
             xacc[j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pick_w<WM, XN>(wf, wm, j_), xf, xacc[j_], 0, 0, 0); \
     }
 
-#if GEMM_PRIO == 1
-    if (wm == 1) __builtin_amdgcn_s_setprio(1);
-#elif GEMM_PRIO == 3
-    if (wm == 1) __builtin_amdgcn_s_setprio(3);
-#endif
     const int nk = g.K / BK;
     stage_a(0, 0);
     stage_w(0, 0);

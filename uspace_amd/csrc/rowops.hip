@@ -72,31 +72,34 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ im
     float* out = tok + (size_t)blockIdx.x * D;
     bf16_t* outb = tok_bf16 ? tok_bf16 + (size_t)blockIdx.x * D : nullptr;
     const float* posr = pos + (size_t)l * D;
+    auto put4 = [&](int d, f32x4 v) {   // D % 4 == 0: 16-byte stores
+        v += *(const f32x4*)(posr + d);
+        *(f32x4*)(out + d) = v;
+        if (outb) {
+            uint2 q;
+            q.x = pack_bf2(v[0], v[1]);
+            q.y = pack_bf2(v[2], v[3]);
+            *(uint2*)(outb + d) = q;
+        }
+    };
     if (l == time_pos) {
         // timestep_embedding (libs/uvit.py:36-43): [cos(t f_k) | sin(t f_k)], f_k = exp(-ln(1e4) k / half)
         const float tv = t[(size_t)b * t_stride];
         const int half = D / 2;
-        for (int d = threadIdx.x; d < D; d += blockDim.x) {
-            float v;
-            if (d < 2 * half) {
-                const int k = d < half ? d : d - half;
-                const float f = expf(-9.210340371976184f * (float)k / (float)half);
-                const float a = tv * f;
-                v = d < half ? cosf(a) : sinf(a);
-            } else {
-                v = 0.f;
+        for (int d = threadIdx.x * 4; d < D; d += blockDim.x * 4) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int dd = d + e;
+                const int k = dd < half ? dd : dd - half;
+                const float a = tv * expf(-9.210340371976184f * (float)k / (float)half);
+                v[e] = dd < half ? cosf(a) : sinf(a);
             }
-            v += posr[d];
-            out[d] = v;
-            if (outb) outb[d] = f2bf(v);
+            put4(d, v);
         }
     } else if (l >= extra_pos && l < extra_pos + n_extra && l != time_pos) {
         const float* src = extra + ((size_t)b * n_extra + (l - extra_pos)) * D;
-        for (int d = threadIdx.x; d < D; d += blockDim.x) {
-            const float v = src[d] + posr[d];
-            out[d] = v;
-            if (outb) outb[d] = f2bf(v);
-        }
+        for (int d = threadIdx.x * 4; d < D; d += blockDim.x * 4) put4(d, *(const f32x4*)(src + d));
     } else {
         // PatchEmbed conv k = s = p (libs/uvit.py:171-178): pixels consumed in (c, i, j) order
         __shared__ float px[64];
@@ -109,13 +112,16 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ im
             px[threadIdx.x] = img[(((size_t)b * C + c) * S + ph * p + i) * S + pwid * p + j];
         }
         __syncthreads();
-        for (int d = threadIdx.x; d < D; d += blockDim.x) {
-            const float* w = pw + (size_t)d * npx;
-            float s = pb[d];
-            for (int e = 0; e < npx; ++e) s += w[e] * px[e];
-            s += posr[d];
-            out[d] = s;
-            if (outb) outb[d] = f2bf(s);
+        for (int d = threadIdx.x * 4; d < D; d += blockDim.x * 4) {
+            f32x4 v = *(const f32x4*)(pb + d);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float* w = pw + (size_t)(d + e) * npx;
+                float s = v[e];
+                for (int q = 0; q < npx; ++q) s += w[q] * px[q];
+                v[e] = s;
+            }
+            put4(d, v);
         }
     }
 }
@@ -124,6 +130,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ im
 // Output head, stage 1: LayerNorm + decoder_pred (D -> PD <= 16) on patch tokens + unpatchify.
 // One wave per patch token; 4 tokens per block.
 // ------------------------------------------------------------------------------------------
+template <int NV>  // float4 per lane: D <= NV*256
 __global__ __launch_bounds__(256) void head_pred_kernel(const float* __restrict__ tok, int L, int extras,
                                                         const float* __restrict__ ng, const float* __restrict__ nb,
                                                         const float* __restrict__ dw, const float* __restrict__ db,
@@ -135,51 +142,55 @@ __global__ __launch_bounds__(256) void head_pred_kernel(const float* __restrict_
     if (idx >= B * npatch) return;
     const int b = idx / npatch, tp = idx % npatch;
     const float* xr = tok + ((size_t)b * L + extras + tp) * D;
+    f32x4 v[NV];
     float s = 0.f;
-    for (int c = lane * 4; c < D; c += 256) {
-        const f32x4 v = *(const f32x4*)(xr + c);
-        s += (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = c < D ? *(const f32x4*)(xr + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
-    for (int c = lane * 4; c < D; c += 256) {
-        const f32x4 v = *(const f32x4*)(xr + c);
-        const float a0 = v[0] - mean, a1 = v[1] - mean, a2 = v[2] - mean, a3 = v[3] - mean;
-        q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
-    const int PD = p * p * C;  // <= 16
-    float acc[16];
 #pragma unroll
-    for (int o = 0; o < 16; ++o) acc[o] = 0.f;
-    for (int c = lane * 4; c < D; c += 256) {
-        const f32x4 v = *(const f32x4*)(xr + c);
-        const f32x4 gg = *(const f32x4*)(ng + c);
-        const f32x4 bb = *(const f32x4*)(nb + c);
-        f32x4 n;
-        n[0] = (v[0] - mean) * rstd * gg[0] + bb[0];
-        n[1] = (v[1] - mean) * rstd * gg[1] + bb[1];
-        n[2] = (v[2] - mean) * rstd * gg[2] + bb[2];
-        n[3] = (v[3] - mean) * rstd * gg[3] + bb[3];
-#pragma unroll
-        for (int o = 0; o < 16; ++o) {
-            if (o < PD) {
-                const f32x4 w = *(const f32x4*)(dw + (size_t)o * D + c);
-                acc[o] += (n[0] * w[0] + n[1] * w[1]) + (n[2] * w[2] + n[3] * w[3]);
-            }
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            const float a0 = v[i][0] - mean, a1 = v[i][1] - mean, a2 = v[i][2] - mean, a3 = v[i][3] - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
         }
     }
-    const int ph = tp / g, pwid = tp % g;
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
 #pragma unroll
-    for (int o = 0; o < 16; ++o) {
-        if (o < PD) {
-            const float r = wave_sum(acc[o]) + db[o];
-            if (lane == 0) {
-                // unpatchify "(p1 p2 C)" (libs/uvit.py:60-62)
-                const int c = o % C, p12 = o / C;
-                const int p1 = p12 / p, p2 = p12 % p;
-                img[(((size_t)b * C + c) * S + ph * p + p1) * S + pwid * p + p2] = r;
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            const f32x4 gg = *(const f32x4*)(ng + c);
+            const f32x4 bb = *(const f32x4*)(nb + c);
+            v[i][0] = (v[i][0] - mean) * rstd * gg[0] + bb[0];
+            v[i][1] = (v[i][1] - mean) * rstd * gg[1] + bb[1];
+            v[i][2] = (v[i][2] - mean) * rstd * gg[2] + bb[2];
+            v[i][3] = (v[i][3] - mean) * rstd * gg[3] + bb[3];
+        }
+    }
+    const int PD = p * p * C;  // <= 16
+    const int ph = tp / g, pwid = tp % g;
+    for (int o = 0; o < PD; ++o) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < D) {
+                const f32x4 w = *(const f32x4*)(dw + (size_t)o * D + c);
+                acc += (v[i][0] * w[0] + v[i][1] * w[1]) + (v[i][2] * w[2] + v[i][3] * w[3]);
             }
+        }
+        const float r = wave_sum(acc) + db[o];
+        if (lane == 0) {
+            // unpatchify "(p1 p2 C)" (libs/uvit.py:60-62)
+            const int c = o % C, p12 = o / C;
+            const int p1 = p12 / p, p2 = p12 % p;
+            img[(((size_t)b * C + c) * S + ph * p + p1) * S + pwid * p + p2] = r;
         }
     }
 }
@@ -320,7 +331,7 @@ extern "C" int uspace_embed_tokens(const float* img, const float* t, int t_strid
                                    float* tok, uint16_t* tok_bf16, int B, int C, int S, int p, int D,
                                    uspace_stream_t stream) {
     if (!img || !t || !patch_w || !patch_b || !pos || !tok) return USPACE_ERR_ARG;
-    if (B <= 0 || C <= 0 || S <= 0 || p <= 0 || D <= 0 || S % p || C * p * p > 64 || n_extra < 0) return USPACE_ERR_ARG;
+    if (B <= 0 || C <= 0 || S <= 0 || p <= 0 || D <= 0 || (D & 3) || S % p || C * p * p > 64 || n_extra < 0) return USPACE_ERR_ARG;
     if (n_extra > 0 && !extra) return USPACE_ERR_ARG;
     const int g = S / p;
     const int L = 1 + n_extra + g * g;
@@ -335,12 +346,16 @@ extern "C" int uspace_output_head(const float* tok, int L, int extras, const flo
                                   float* scratch, float* out, int B, int C, int S, int p, int D, float eps,
                                   uspace_stream_t stream) {
     if (!tok || !norm_g || !norm_b || !dec_w || !dec_b || !conv_w || !conv_b || !scratch || !out) return USPACE_ERR_ARG;
-    if (B <= 0 || (D & 3) || S % p || p * p * C > 16) return USPACE_ERR_ARG;
+    if (B <= 0 || (D & 3) || D > 2048 || S % p || p * p * C > 16) return USPACE_ERR_ARG;
     const int g = S / p;
     if (extras + g * g != L) return USPACE_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(head_pred_kernel, dim3(us_cdiv(B * g * g, 4)), dim3(256), 0, s, tok, L, extras, norm_g, norm_b,
-                       dec_w, dec_b, scratch, B, C, S, p, D, eps);
+    const dim3 hgrid(us_cdiv(B * g * g, 4)), hblock(256);
+    if (D <= 256) hipLaunchKernelGGL(head_pred_kernel<1>, hgrid, hblock, 0, s, tok, L, extras, norm_g, norm_b, dec_w, dec_b, scratch, B, C, S, p, D, eps);
+    else if (D <= 512) hipLaunchKernelGGL(head_pred_kernel<2>, hgrid, hblock, 0, s, tok, L, extras, norm_g, norm_b, dec_w, dec_b, scratch, B, C, S, p, D, eps);
+    else if (D <= 1024) hipLaunchKernelGGL(head_pred_kernel<4>, hgrid, hblock, 0, s, tok, L, extras, norm_g, norm_b, dec_w, dec_b, scratch, B, C, S, p, D, eps);
+    else if (D <= 2048) hipLaunchKernelGGL(head_pred_kernel<8>, hgrid, hblock, 0, s, tok, L, extras, norm_g, norm_b, dec_w, dec_b, scratch, B, C, S, p, D, eps);
+    else return USPACE_ERR_ARG;
     US_CHECK_LAUNCH();
     const long total = (long)B * C * S * S;
     hipLaunchKernelGGL(conv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, scratch, conv_w, conv_b,
