@@ -119,6 +119,9 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        _w = torch.zeros(8, device=dev)                       # create the RCCL communicator outside the timed region
+        dist.all_gather([torch.empty_like(_w) for _ in range(world)], _w)
+        torch.cuda.synchronize()
 
     from uspace_amd import _hip
     from uspace_amd.sampling import gather_batch
@@ -133,6 +136,7 @@ def main():
         from uspace_amd.flow_matching_t2i import CNF
     else:
         from uspace_amd.flow_matching import CNF
+    net.use_graph = False      # eager launches: the roofline line records HIP events around individual GEMM launches
     cnf = CNF(net)
     B = args.batch
     g = torch.Generator().manual_seed(7 + rank)

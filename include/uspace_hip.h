@@ -165,6 +165,17 @@ typedef struct uspace_uvit_io {
 USPACE_API int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* blob, void* workspace,
                         size_t workspace_bytes, const uspace_uvit_io* io, int B, uspace_stream_t stream);
 
+/* hipGraph form of the forward.  _create() runs the forward once eagerly on `capture_stream` (must be a
+ * real, non-NULL stream), then captures the same launch sequence and instantiates it.  The pointers in
+ * `io`, the blob and the workspace are baked in: keep them alive and stable, refresh their CONTENTS
+ * before each _launch().  Replaces ~160 host launches per network evaluation with one. */
+typedef struct uspace_uvit_graph uspace_uvit_graph;
+USPACE_API int uspace_uvit_graph_create(const uspace_uvit_config* cfg, const void* blob, void* workspace,
+                                        size_t workspace_bytes, const uspace_uvit_io* io, int B,
+                                        uspace_stream_t capture_stream, uspace_uvit_graph** out);
+USPACE_API int uspace_uvit_graph_launch(uspace_uvit_graph* g, uspace_stream_t stream);
+USPACE_API int uspace_uvit_graph_destroy(uspace_uvit_graph* g);
+
 /* ---------------------------------------------------------------------------------------
  * Measurement aid (bench.py): record HIP events, on the launching stream, around every
  * uspace_gemm_bf16 launch whose (epi_flags, N, K) match, up to max_launches; _end() waits for

@@ -209,3 +209,40 @@ def test_cpu_tensor_is_rejected_loudly(golden_dir):
     net = build("uvit", sd, num_classes=-1, **TINY)
     with pytest.raises(_hip.UspaceHipError):
         net(torch.from_numpy(z["x"]), torch.zeros(3), None, edit_loc=None)
+
+
+def test_hipgraph_replay_is_bit_identical_to_eager(golden_dir):
+    """Plain evaluations replay a captured hipGraph; results equal the eager launch sequence bit for bit,
+    across repeated calls, changing inputs / timesteps, batch-size changes and a weight update."""
+    z, sd = load_sd(golden_dir, "tiny_t2i.npz")
+    net = build("uvit_t2i", sd, clip_dim=64, num_clip_token=77, **TINY)
+    x, ctx = dev(z["x"]), dev(z["ctx"])
+    outs = {}
+    for use in (False, True):
+        net.use_graph = use
+        res = []
+        for tv in (0.1, 0.62, 0.62, 0.9):
+            o, _ = net(x, expand_t(tv, 3), context=ctx)
+            res.append(o)
+        o2, _ = net(x[:2].contiguous(), expand_t(0.3, 2), context=ctx[:2].contiguous())     # other batch size
+        o3, _ = net(x * 0.5, expand_t(0.62, 3), context=ctx)                                 # other input, same graph
+        outs[use] = res + [o2, o3]
+    for a, b in zip(outs[False], outs[True]):
+        assert torch.equal(a, b)
+    assert torch.equal(outs[True][1], outs[True][2]) and not torch.equal(outs[True][0], outs[True][1])
+    held = outs[True][0].clone()
+    net(x, expand_t(0.5, 3), context=ctx)                    # a later replay must not clobber earlier results
+    assert torch.equal(held, outs[True][0])
+    with torch.no_grad():
+        net.decoder_pred.bias.add_(0.5)                      # repack -> stale graphs dropped, new one captured
+    net.use_graph = True
+    g, _ = net(x, expand_t(0.62, 3), context=ctx)
+    net.use_graph = False
+    e, _ = net(x, expand_t(0.62, 3), context=ctx)
+    assert torch.equal(g, e) and not torch.equal(g, outs[True][1])
+    # hooked evaluations stay on the eager path and still work with use_graph on
+    net.use_graph = True
+    ids = [z2 for z2 in (np.array([3]), np.array([], dtype=np.int64), np.array([5]))]
+    h, _ = net(x, expand_t(0.3, 3), context=ctx, dissect_name="p2p", fm_direction="decode", t_edit=0.5, block_id="all",
+               target_context_ids=ids, token_kwargs=dict(token_dissect="p2p_rescale", p2p_multiplier=3.0))
+    assert bool(torch.isfinite(h).all())

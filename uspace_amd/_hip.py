@@ -53,6 +53,10 @@ SIGNATURES = {
     "uspace_uvit_workspace_bytes": (_SZ, [ctypes.POINTER(UvitConfig), _I]),
     "uspace_uvit_pack_weights": (_I, [ctypes.POINTER(UvitConfig), ctypes.POINTER(_P), _I, _P, _SZ, _P]),
     "uspace_uvit_forward": (_I, [ctypes.POINTER(UvitConfig), _P, _P, _SZ, ctypes.POINTER(UvitIO), _I, _P]),
+    "uspace_uvit_graph_create": (_I, [ctypes.POINTER(UvitConfig), _P, _P, _SZ, ctypes.POINTER(UvitIO), _I, _P,
+                                      ctypes.POINTER(_P)]),
+    "uspace_uvit_graph_launch": (_I, [_P, _P]),
+    "uspace_uvit_graph_destroy": (_I, [_P]),
     "uspace_prof_gemm_begin": (_I, [_I, _I, _I, _I]),
     "uspace_prof_gemm_end": (_I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I)]),
 }

@@ -260,3 +260,58 @@ extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* bl
                               (float*)(ws + w.head), io->out, B, c.in_chans, c.img_size, c.patch_size, D, 1e-5f, stream));
     return USPACE_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// hipGraph form of the forward: the ~160 dependent launches of one network evaluation are
+// captured once (per batch size / hook mode) and replayed with a single hipGraphLaunch, which
+// removes the host launch cost that dominates small batches (B = 4..16 trajectories).
+// The io pointers are baked into the graph: the caller keeps them stable and refreshes their
+// contents (x, t, context, mid_delta) before each replay.
+// ------------------------------------------------------------------------------------------
+struct uspace_uvit_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+extern "C" int uspace_uvit_graph_create(const uspace_uvit_config* cfg, const void* blob, void* workspace,
+                                        size_t workspace_bytes, const uspace_uvit_io* io, int B,
+                                        uspace_stream_t capture_stream, uspace_uvit_graph** out) {
+    if (!out || !capture_stream) return USPACE_ERR_ARG;   // the legacy NULL stream cannot be captured
+    *out = nullptr;
+    hipStream_t s = (hipStream_t)capture_stream;
+    // one eager run first: first-use initialisation (kernel attributes) is not capturable
+    int rc = uspace_uvit_forward(cfg, blob, workspace, workspace_bytes, io, B, capture_stream);
+    if (rc != USPACE_OK) return rc;
+    if (hipStreamSynchronize(s) != hipSuccess) return USPACE_ERR_LAUNCH;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) return USPACE_ERR_LAUNCH;
+    rc = uspace_uvit_forward(cfg, blob, workspace, workspace_bytes, io, B, capture_stream);
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rc != USPACE_OK || e != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc != USPACE_OK ? rc : USPACE_ERR_LAUNCH;
+    }
+    hipGraphExec_t exec = nullptr;
+    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGraphDestroy(graph);
+        return USPACE_ERR_LAUNCH;
+    }
+    uspace_uvit_graph* h = new uspace_uvit_graph;
+    h->graph = graph;
+    h->exec = exec;
+    *out = h;
+    return USPACE_OK;
+}
+
+extern "C" int uspace_uvit_graph_launch(uspace_uvit_graph* g, uspace_stream_t stream) {
+    if (!g || !g->exec) return USPACE_ERR_ARG;
+    return hipGraphLaunch(g->exec, (hipStream_t)stream) == hipSuccess ? USPACE_OK : USPACE_ERR_LAUNCH;
+}
+
+extern "C" int uspace_uvit_graph_destroy(uspace_uvit_graph* g) {
+    if (!g) return USPACE_OK;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    return USPACE_OK;
+}

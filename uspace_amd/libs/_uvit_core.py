@@ -70,6 +70,8 @@ class UViTBase(nn.Module):
         self._packed = None          # (device, versions, blob)
         self._workspace = {}         # B -> uint8 tensor
         self._delta_cache = {}
+        self.use_graph = True        # replay a captured hipGraph for plain (un-hooked) evaluations
+        self._graphs = {}            # (B, device, blob ptr, has ctx) -> _GraphEntry (at most _MAX_GRAPHS)
 
     # ------------------------------------------------------------------ parameter tree
     def _build_tree(self, extra_builder):
@@ -203,6 +205,56 @@ class UViTBase(nn.Module):
             self._workspace = {key: ws}     # keep one batch size resident
         return ws
 
+    # ------------------------------------------------------------------ hipGraph replay (plain evaluations)
+    _MAX_GRAPHS = 4
+
+    def _graph_entry(self, B, dev, blob, context):
+        key = (B, str(dev), blob.data_ptr(), context is not None)
+        ent = self._graphs.get(key)
+        if ent is not None:
+            return ent
+        stale = [k for k in self._graphs if k[2] != blob.data_ptr()]       # weights were repacked
+        for k in stale:
+            self._graphs.pop(k).destroy()
+        while len(self._graphs) >= self._MAX_GRAPHS:
+            self._graphs.pop(next(iter(self._graphs))).destroy()
+        L = _hip.lib()
+        ent = _GraphEntry()
+        ent.x = torch.empty(B, self.in_chans, self.img_size, self.img_size, dtype=torch.float32, device=dev)
+        ent.t = torch.zeros(1, dtype=torch.float32, device=dev)
+        ent.ctx = torch.empty_like(context) if context is not None else None
+        ent.out = torch.empty_like(ent.x)
+        nbytes = L.uspace_uvit_workspace_bytes(ctypes.byref(self._cfg), B)
+        ent.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ent.blob = blob
+        ent.io = _hip.UvitIO(_hip.ptr(ent.x), _hip.ptr(ent.t), 0, _hip.ptr(ent.ctx), None, 0.0, None, None,
+                             _hip.ptr(ent.out))
+        cur = torch.cuda.current_stream(dev)
+        cap = torch.cuda.Stream(device=dev)            # capture needs a real (non-NULL) stream
+        ent.x.zero_()
+        if ent.ctx is not None:
+            ent.ctx.zero_()
+        cap.wait_stream(cur)
+        handle = ctypes.c_void_p()
+        rc = L.uspace_uvit_graph_create(ctypes.byref(self._cfg), _hip.ptr(blob), _hip.ptr(ent.ws), ent.ws.numel(),
+                                        ctypes.byref(ent.io), B, ctypes.c_void_p(cap.cuda_stream), ctypes.byref(handle))
+        _hip.check(rc, "uspace_uvit_graph_create")
+        cap.synchronize()
+        ent.handle = handle
+        self._graphs[key] = ent
+        return ent
+
+    def _run_graph(self, xin, t, context, B, dev, out_dtype):
+        blob = self._packed_blob(dev)
+        ent = self._graph_entry(B, dev, blob, context)
+        ent.x.copy_(xin, non_blocking=True)
+        ent.t.copy_(t.reshape(-1)[:1], non_blocking=True)
+        if context is not None:
+            ent.ctx.copy_(context, non_blocking=True)
+        _hip.check(_hip.lib().uspace_uvit_graph_launch(ent.handle, _hip.stream_ptr()), "uspace_uvit_graph_launch")
+        out = ent.out.clone()                     # the caller owns its result (solvers keep several alive)
+        return out if out_dtype == torch.float32 else out.to(out_dtype)
+
     # ------------------------------------------------------------------ the single HIP call
     def _run(self, x, timesteps, context=None, mid_delta=None, mid_scale=0.0, mid_tap=None, key_scale=None):
         _hip.require_device(x, "x")
@@ -223,6 +275,9 @@ class UViTBase(nn.Module):
             t_stride = t.stride(0)
             if t_stride not in (0, 1):
                 t = t.contiguous(); t_stride = 1
+        plain = mid_delta is None and mid_tap is None and key_scale is None
+        if self.use_graph and plain and t_stride == 0:
+            return self._run_graph(xin, t, context, B, dev, x.dtype)
         out = torch.empty(B, self.in_chans, self.img_size, self.img_size, dtype=torch.float32, device=dev)
         blob = self._packed_blob(dev)
         ws = self._workspace_for(B, dev)
@@ -231,6 +286,23 @@ class UViTBase(nn.Module):
         _hip.check(_hip.lib().uspace_uvit_forward(ctypes.byref(self._cfg), _hip.ptr(blob), _hip.ptr(ws), ws.numel(),
                                                   ctypes.byref(io), B, _hip.stream_ptr()), "uspace_uvit_forward")
         return out if x.dtype == torch.float32 else out.to(x.dtype)
+
+
+class _GraphEntry:
+    """Static buffers + instantiated hipGraph of one (batch size, weights) combination."""
+
+    handle = None
+
+    def destroy(self):
+        if self.handle is not None:
+            _hip.lib().uspace_uvit_graph_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
 
 
 def host_timestep(timesteps, kwargs):
