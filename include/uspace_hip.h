@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define USPACE_ABI_VERSION 1
+#define USPACE_ABI_VERSION 2
 
 #define USPACE_OK 0
 #define USPACE_ERR_ARG (-1)         /* bad pointer / size / unsupported shape */
@@ -97,6 +97,12 @@ USPACE_API int uspace_output_head(const float* tok, int L, int extras, const flo
 USPACE_API int uspace_add_broadcast(float* x, uint16_t* x_bf16, const float* delta, float scale,
                          int B, long per_sample, uspace_stream_t stream);
 
+/* Same with a per-sample factor: x[b, i] += scale * row_scale[b] * delta[i] (row_scale: device float[B] or
+ * NULL).  Lets the reference's sweep over `write_scales` (tools/utils_vis.py:189-198: nine full solves of
+ * the same z) run as ONE solve over 9*B rows. */
+USPACE_API int uspace_add_broadcast_rows(float* x, uint16_t* x_bf16, const float* delta, float scale,
+                                         const float* row_scale, int B, long per_sample, uspace_stream_t stream);
+
 /* fp32 -> bf16 (round to nearest even). */
 USPACE_API int uspace_cast_f32_bf16(const float* src, uint16_t* dst, long n, uspace_stream_t stream);
 
@@ -160,6 +166,7 @@ typedef struct uspace_uvit_io {
     float* mid_tap;          /* optional [B,L,D] fp32: copy of the mid_block output (hook "read" mode) */
     const float* key_scale;  /* optional [depth+1, B, L] fp32 attention-map column factors per block */
     float* out;              /* [B,C,S,S] fp32 */
+    const float* mid_row_scale; /* optional [B] fp32: per-sample factor multiplying mid_scale */
 } uspace_uvit_io;
 
 USPACE_API int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* blob, void* workspace,

@@ -143,3 +143,40 @@ def test_cnf_t2i_sets_direction_and_edits(golden_dir):
     f_ref = lambda t, y: O.uvit_forward(spec, sd, y, np.float32(t), context=z["ctx"], **okw)
     ref = OO.solve(f_ref, z["x"], 0.0, 1.0, method="euler", step_size=0.1)
     assert rel_l2(edited.cpu().numpy(), ref) < 1e-2
+
+
+def test_batched_write_scales_sweep_equals_sequential_solves(golden_dir):
+    """tools/utils_vis.py:189-198 runs one full solve per write_scale; decode_write_scales() runs them as one
+    solve with a per-row hook scale.  Same results (up to GEMM tile-shape summation grouping) at every hook
+    location, and scale 0 rows equal the un-hooked solve."""
+    import os
+    import tempfile
+    from uspace_amd.flow_matching import CNF
+    from uspace_amd.tools.utils_uvit import get_nnet
+    z, sd = load_sd(golden_dir, "tiny_u.npz")
+    hz = np.load(os.path.join(golden_dir, "hooks_u.npz"))
+    net = get_nnet("uvit", num_classes=-1, **TINY)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.cuda().eval()
+    cnf = CNF(net)
+    x0 = torch.from_numpy(z["x"]).cuda()
+    scales = [-2.0, -0.5, 0.0, 1.0, 3.0]
+    sk = _solver_kwargs(solver_fix_step=0.1)
+    with tempfile.TemporaryDirectory() as d:
+        for loc, table in (("head", hz["img_attr"]), ("tail", hz["img_attr"]), ("mid", hz["tok_attr"])):
+            root = os.path.join(d, loc)
+            os.makedirs(root)
+            for k in range(0, 11):
+                np.save(os.path.join(root, f"delta_{k / 10:.2f}.npy"), table)
+            kw = dict(dissect_task="uspace_uvit", dissect_name="write_attr", t_edit=0.4, write_path_root=root,
+                      edit_loc=loc, ith_attr="1_3", solver_kwargs=sk)
+            seq = torch.stack([cnf.decode(x0, None, write_scale=s, **kw) for s in scales])
+            bat = cnf.decode_write_scales(x0, None, scales, **kw)
+            assert bat.shape == seq.shape
+            assert rel_l2(bat.cpu().numpy(), seq.cpu().numpy()) < 2e-3, loc
+            plain = cnf.decode(x0, None, dissect_name="none", edit_loc=None, solver_kwargs=sk)
+            assert rel_l2(bat[2].cpu().numpy(), plain.cpu().numpy()) < 2e-3
+            assert rel_l2(bat[4].cpu().numpy(), plain.cpu().numpy()) > 1e-3
+    with pytest.raises(ValueError):
+        net(x0, torch.tensor(0.2, device="cuda").expand(3), None, dissect_task="uspace_uvit", dissect_name="write_attr",
+            t_edit=0.4, write_path_root="/nonexistent", edit_loc="head", ith_attr=1, write_scale=[1.0, 2.0])

@@ -30,7 +30,8 @@ class UvitIO(ctypes.Structure):
     _fields_ = [
         ("x", ctypes.c_void_p), ("t", ctypes.c_void_p), ("t_stride", ctypes.c_int),
         ("context", ctypes.c_void_p), ("mid_delta", ctypes.c_void_p), ("mid_scale", ctypes.c_float),
-        ("mid_tap", ctypes.c_void_p), ("key_scale", ctypes.c_void_p), ("out", ctypes.c_void_p)]
+        ("mid_tap", ctypes.c_void_p), ("key_scale", ctypes.c_void_p), ("out", ctypes.c_void_p),
+        ("mid_row_scale", ctypes.c_void_p)]
 
 
 _P, _I, _L, _F, _SZ = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
@@ -44,6 +45,7 @@ SIGNATURES = {
     "uspace_embed_tokens": (_I, [_P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "uspace_output_head": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "uspace_add_broadcast": (_I, [_P, _P, _P, _F, _I, _L, _P]),
+    "uspace_add_broadcast_rows": (_I, [_P, _P, _P, _F, _P, _I, _L, _P]),
     "uspace_cast_f32_bf16": (_I, [_P, _P, _L, _P]),
     "uspace_ode_combine": (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _L, _P]),
     "uspace_ode_error_norm": (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _F, _F, _L, _P, _P, _P]),
@@ -77,7 +79,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
-        if L.uspace_abi_version() != 1:
+        if L.uspace_abi_version() != 2:
             raise UspaceHipError("libuspace_hip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -148,13 +150,16 @@ def attention(qkv, B, L, H, key_scale=None):
     return out
 
 
-def add_broadcast(x, delta, scale, x_bf16=None):
+def add_broadcast(x, delta, scale, x_bf16=None, row_scale=None):
+    """x[b] += scale * (row_scale[b] if given) * delta, in place."""
     require_device(x, "x")
     B = x.shape[0]
     per = x.numel() // B
     assert delta.numel() == per and delta.dtype == torch.float32 and x.dtype == torch.float32
-    check(lib().uspace_add_broadcast(ptr(x), ptr(x_bf16), ptr(delta), float(scale), B, per, stream_ptr()),
-          "uspace_add_broadcast")
+    if row_scale is not None:
+        assert row_scale.numel() == B and row_scale.dtype == torch.float32 and row_scale.is_cuda
+    check(lib().uspace_add_broadcast_rows(ptr(x), ptr(x_bf16), ptr(delta), float(scale), ptr(row_scale), B, per,
+                                          stream_ptr()), "uspace_add_broadcast_rows")
     return x
 
 

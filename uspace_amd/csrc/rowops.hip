@@ -214,15 +214,18 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
     out[i] = s;
 }
 
-// x[b, i] += scale * delta[i]; optional bf16 copy refresh. per_sample % 4 == 0.
+// x[b, i] += scale_b * delta[i] (scale_b = scale * row_scale[b] when row_scale != NULL); optional bf16 copy
+// refresh. per_sample % 4 == 0.
 __global__ __launch_bounds__(256) void add_bcast_kernel(float* __restrict__ x, bf16_t* __restrict__ xb,
                                                         const float* __restrict__ delta, float scale,
+                                                        const float* __restrict__ row_scale,
                                                         long per_sample4, long total4) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const long j = i % per_sample4;
         f32x4 v = ((f32x4*)x)[i];
         const f32x4 d = ((const f32x4*)delta)[j];
-        v += d * scale;
+        const float sc = row_scale ? scale * row_scale[i / per_sample4] : scale;
+        v += d * sc;
         ((f32x4*)x)[i] = v;
         if (xb) {
             uint2 p;
@@ -234,9 +237,10 @@ __global__ __launch_bounds__(256) void add_bcast_kernel(float* __restrict__ x, b
 }
 
 __global__ __launch_bounds__(256) void add_bcast_tail_kernel(float* x, bf16_t* xb, const float* delta, float scale,
-                                                             long per_sample, long total) {
+                                                             const float* row_scale, long per_sample, long total) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const float v = x[i] + scale * delta[i % per_sample];
+        const float sc = row_scale ? scale * row_scale[i / per_sample] : scale;
+        const float v = x[i] + sc * delta[i % per_sample];
         x[i] = v;
         if (xb) xb[i] = f2bf(v);
     }
@@ -366,15 +370,20 @@ extern "C" int uspace_output_head(const float* tok, int L, int extras, const flo
 
 extern "C" int uspace_add_broadcast(float* x, uint16_t* x_bf16, const float* delta, float scale, int B,
                                     long per_sample, uspace_stream_t stream) {
+    return uspace_add_broadcast_rows(x, x_bf16, delta, scale, nullptr, B, per_sample, stream);
+}
+
+extern "C" int uspace_add_broadcast_rows(float* x, uint16_t* x_bf16, const float* delta, float scale,
+                                         const float* row_scale, int B, long per_sample, uspace_stream_t stream) {
     if (!x || !delta || B <= 0 || per_sample <= 0) return USPACE_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const long total = (long)B * per_sample;
     if ((per_sample & 3) == 0) {
         hipLaunchKernelGGL(add_bcast_kernel, dim3(grid_for(total >> 2)), dim3(256), 0, s, x, x_bf16, delta, scale,
-                           per_sample >> 2, total >> 2);
+                           row_scale, per_sample >> 2, total >> 2);
     } else {
         hipLaunchKernelGGL(add_bcast_tail_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, x_bf16, delta, scale,
-                           per_sample, total);
+                           row_scale, per_sample, total);
     }
     US_CHECK_LAUNCH();
     return USPACE_OK;

@@ -253,7 +253,7 @@ extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* bl
                     return USPACE_ERR_LAUNCH;
             }
             if (io->mid_delta)  // u-space write hook at the mid block (libs/uvit.py:336, libs/dissection.py:157)
-                US_TRY(uspace_add_broadcast(x, xb, io->mid_delta, io->mid_scale, B, (long)L * D, stream));
+                US_TRY(uspace_add_broadcast_rows(x, xb, io->mid_delta, io->mid_scale, io->mid_row_scale, B, (long)L * D, stream));
         }
     }
     US_TRY(uspace_output_head(x, L, m.extras, PF(m.ng), PF(m.nb), PF(m.dw), PF(m.db), PF(m.convw), PF(m.convb),

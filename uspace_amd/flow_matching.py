@@ -121,3 +121,15 @@ class CNF(CNFBase):
         return self._fixadp(func, z, 0.0, t_mid, 1.0, kwargs)
 
     sample_ode = decode
+
+    def decode_write_scales(self, z, y, write_scales, **kwargs):
+        """The reference's sweep ``for write_scale in write_scales: decode(z, write_scale=...)``
+        (tools/utils_vis.py:189-198, nine full solves of the same z) as ONE solve over len(scales)*B rows
+        with a per-row hook scale.  Returns [n_scales, B, C, H, W].  Exactly equal to the sequential sweep
+        for fixed-step solvers; adaptive solvers would share one step-size sequence across the scales."""
+        n, B = len(write_scales), z.shape[0]
+        rows = torch.as_tensor([float(s) for s in write_scales], dtype=torch.float32).repeat_interleave(B)
+        zz = z.repeat(n, 1, 1, 1)
+        yy = y.repeat(n) if torch.is_tensor(y) else y
+        out = self.decode(zz, yy, **dict(kwargs, write_scale=rows))
+        return out.view(n, B, *z.shape[1:])

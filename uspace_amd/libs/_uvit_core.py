@@ -228,7 +228,7 @@ class UViTBase(nn.Module):
         ent.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         ent.blob = blob
         ent.io = _hip.UvitIO(_hip.ptr(ent.x), _hip.ptr(ent.t), 0, _hip.ptr(ent.ctx), None, 0.0, None, None,
-                             _hip.ptr(ent.out))
+                             _hip.ptr(ent.out), None)
         cur = torch.cuda.current_stream(dev)
         cap = torch.cuda.Stream(device=dev)            # capture needs a real (non-NULL) stream
         ent.x.zero_()
@@ -256,7 +256,8 @@ class UViTBase(nn.Module):
         return out if out_dtype == torch.float32 else out.to(out_dtype)
 
     # ------------------------------------------------------------------ the single HIP call
-    def _run(self, x, timesteps, context=None, mid_delta=None, mid_scale=0.0, mid_tap=None, key_scale=None):
+    def _run(self, x, timesteps, context=None, mid_delta=None, mid_scale=0.0, mid_tap=None, key_scale=None,
+             mid_row_scale=None):
         _hip.require_device(x, "x")
         if x.dim() != 4 or x.shape[1] != self.in_chans or x.shape[2] != self.img_size or x.shape[3] != self.img_size:
             raise ValueError(f"x must be [B,{self.in_chans},{self.img_size},{self.img_size}], got {tuple(x.shape)}")
@@ -282,7 +283,8 @@ class UViTBase(nn.Module):
         blob = self._packed_blob(dev)
         ws = self._workspace_for(B, dev)
         io = _hip.UvitIO(_hip.ptr(xin), _hip.ptr(t), t_stride, _hip.ptr(context), _hip.ptr(mid_delta),
-                         float(mid_scale), _hip.ptr(mid_tap), _hip.ptr(key_scale), _hip.ptr(out))
+                         float(mid_scale), _hip.ptr(mid_tap), _hip.ptr(key_scale), _hip.ptr(out),
+                         _hip.ptr(mid_row_scale))
         _hip.check(_hip.lib().uspace_uvit_forward(ctypes.byref(self._cfg), _hip.ptr(blob), _hip.ptr(ws), ws.numel(),
                                                   ctypes.byref(io), B, _hip.stream_ptr()), "uspace_uvit_forward")
         return out if x.dtype == torch.float32 else out.to(x.dtype)

@@ -40,12 +40,19 @@ def select_rows(table, ith):
 
 
 class HookPlan:
-    """What one forward has to do at the hooked location."""
+    """What one forward has to do at the hooked location.  ``scale`` is a float, or -- extension for the
+    batched write_scales sweep -- a per-sample sequence (``row_scales``, with ``scale`` = 1)."""
 
-    __slots__ = ("kind", "path", "ith", "scale")
+    __slots__ = ("kind", "path", "ith", "scale", "row_scales")
 
     def __init__(self, kind, path=None, ith=None, scale=0.0):
-        self.kind, self.path, self.ith, self.scale = kind, path, ith, scale
+        self.kind, self.path, self.ith = kind, path, ith
+        if isinstance(scale, (int, float)):
+            self.scale, self.row_scales = float(scale), None
+        else:
+            self.scale = 1.0
+            self.row_scales = np.asarray(
+                scale.detach().cpu().numpy() if torch.is_tensor(scale) else scale, dtype=np.float32).reshape(-1)
 
 
 def plan_uspace_hook(timestep_digit, kwargs):
@@ -63,13 +70,13 @@ def plan_uspace_hook(timestep_digit, kwargs):
         if not should_edit(timestep_digit, kwargs.get("t_edit")):
             return None
         return HookPlan("write", os.path.join(kwargs.get("write_path_root"), f"delta_{timestep_digit}.npy"),
-                        kwargs.get("ith_attr"), float(kwargs.get("write_scale")))
+                        kwargs.get("ith_attr"), kwargs.get("write_scale"))
     if name == "write_pca":
         if not should_edit(timestep_digit, kwargs.get("t_edit")):
             return None
         return HookPlan("write", os.path.join(kwargs.get("write_path_root"),
                                               f"pca{kwargs.get('pca_n')}_{timestep_digit}.npy"),
-                        kwargs.get("ith_component"), float(kwargs.get("write_scale")))
+                        kwargs.get("ith_component"), kwargs.get("write_scale"))
     raise ValueError(f"dissect_name should be read or write, here is {name}")
 
 

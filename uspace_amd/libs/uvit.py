@@ -65,19 +65,25 @@ class UViT(UViTBase):
             raise ValueError("class-conditional model called without y")
 
         mid_delta, mid_scale, mid_tap = None, 0.0, None
+        rows = None
+        if plan is not None and plan.kind == "write" and plan.row_scales is not None:
+            if plan.row_scales.size != B:
+                raise ValueError(f"write_scale has {plan.row_scales.size} entries for a batch of {B}")
+            rows = torch.from_numpy(plan.row_scales).to(dev)
         if plan is not None and edit_loc == "head":
             if plan.kind == "read":
                 dissection.save_activation(plan.path, x)
             else:
                 delta = self._deltas().get(plan.path, plan.ith, dev, x[0].numel())
-                x = _hip.add_broadcast(x.detach().to(torch.float32).clone(), delta, plan.scale)
+                x = _hip.add_broadcast(x.detach().to(torch.float32).clone(), delta, plan.scale, row_scale=rows)
         if plan is not None and edit_loc == "mid":
             if plan.kind == "read":
                 mid_tap = torch.empty(B, self.seq_len, self.embed_dim, dtype=torch.float32, device=dev)
             else:
                 mid_delta = self._deltas().get(plan.path, plan.ith, dev, self.seq_len * self.embed_dim)
                 mid_scale = plan.scale
-        out = self._run(x, timesteps, context=label_tok, mid_delta=mid_delta, mid_scale=mid_scale, mid_tap=mid_tap)
+        out = self._run(x, timesteps, context=label_tok, mid_delta=mid_delta, mid_scale=mid_scale, mid_tap=mid_tap,
+                        mid_row_scale=rows if mid_delta is not None else None)
         if mid_tap is not None:
             dissection.save_activation(plan.path, mid_tap)
         if plan is not None and edit_loc == "tail":
@@ -85,7 +91,7 @@ class UViT(UViTBase):
                 dissection.save_activation(plan.path, out)
             else:
                 delta = self._deltas().get(plan.path, plan.ith, dev, out[0].numel())
-                out = _hip.add_broadcast(out, delta, plan.scale)
+                out = _hip.add_broadcast(out, delta, plan.scale, row_scale=rows)
         return out, None
 
     def _deltas(self):
