@@ -103,6 +103,13 @@ USPACE_API int uspace_add_broadcast(float* x, uint16_t* x_bf16, const float* del
 USPACE_API int uspace_add_broadcast_rows(float* x, uint16_t* x_bf16, const float* delta, float scale,
                                          const float* row_scale, int B, long per_sample, uspace_stream_t stream);
 
+/* Attribute-direction statistics kept on the device (reference: tools/utils_attr.py:124-145 computes
+ * mean(feat[attr==1]) - mean(feat[attr==0]) in numpy from activations the read hook staged through disk):
+ *   pos_sum[a, f] += sum_n [attr[n,a] == 1] * feat[n, f];  neg_sum likewise for attr == 0.
+ * feat [B, F] fp32, attr [B, A] int32, pos_sum / neg_sum [A, F] fp32 (caller zero-initialises). F % 4 == 0. */
+USPACE_API int uspace_direction_accumulate(const float* feat, const int* attr, float* pos_sum, float* neg_sum,
+                                           int B, long F, int A, uspace_stream_t stream);
+
 /* fp32 -> bf16 (round to nearest even). */
 USPACE_API int uspace_cast_f32_bf16(const float* src, uint16_t* dst, long n, uspace_stream_t stream);
 

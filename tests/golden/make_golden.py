@@ -17,6 +17,7 @@ What is pinned:
                                     the add applied by a forward hook, because the reference's
                                     own reader raises EinopsError on [n,L,D] deltas)
   p2p_t2i                           tools/utils_t2i.py:265 attention-map hook
+  attr_directions                   tools/utils_attr.py:124 mean(pos) - mean(neg) attribute directions
   big_{S,L}_{u,t}                   seed-regenerated weights (sha256 pinned) -> out, B=2
   euler20_S_u                       BASELINE config 1: 20 fixed Euler steps, B=4, driven by
                                     a plain loop written here around the reference nnet
@@ -365,6 +366,32 @@ def make_euler20(uvit, timing):
     timing["cfg1_images_per_s"] = 4.0 / float(np.sum(per))
 
 
+def make_attr_directions():
+    """tools/utils_attr.py:124-145 cal_delta_direction on synthetic features: mean(pos) - mean(neg) per
+    attribute (the direction files the write hook consumes)."""
+    import importlib
+    ua = importlib.import_module("tools.utils_attr")
+    rng = np.random.default_rng(5)
+    N, T = 37, 3
+    out = {}
+    for tag, adim, fshape in (("celeba", 40, (4, 8, 8)), ("ffhq", 11, (9, 16))):
+        attrs = (rng.random((N, adim)) < 0.4).astype(np.int64)
+        attrs[:, 1] = 1          # an attribute with no negative example (mean of empty -> nan in the reference)
+        attrs[rng.integers(0, N, 5), 2] = -1   # values other than 0/1 belong to neither side
+        feats = rng.standard_normal((N, T) + fshape).astype(np.float32)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            deltas = np.concatenate([ua.cal_delta_direction(a, attrs, feats) for a in range(adim)], axis=0)
+        out[f"{tag}_attrs"], out[f"{tag}_feats"], out[f"{tag}_delta"] = attrs, feats, deltas.astype(np.float32)
+    try:
+        ua.cal_delta_direction(0, np.zeros((4, 7), np.int64), np.zeros((4, 1, 2), np.float32))
+        raise SystemExit("expected ValueError for an attribute table that is neither CelebA-40 nor FFHQ-11")
+    except ValueError:
+        pass
+    save("attr_directions.npz", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-large", action="store_true")
@@ -376,6 +403,7 @@ def main():
     make_tiny_u_cond(uvit)
     mt, xt, ctx = make_tiny_t2i(uvit_t2i)
     make_p2p_t2i(mt, xt, ctx)
+    make_attr_directions()
     if not args.skip_large:
         timing = dict(threads=torch.get_num_threads(), nproc=os.cpu_count(),
                       cpu=[l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0],

@@ -180,3 +180,63 @@ def test_batched_write_scales_sweep_equals_sequential_solves(golden_dir):
     with pytest.raises(ValueError):
         net(x0, torch.tensor(0.2, device="cuda").expand(3), None, dissect_task="uspace_uvit", dissect_name="write_attr",
             t_edit=0.4, write_path_root="/nonexistent", edit_loc="head", ith_attr=1, write_scale=[1.0, 2.0])
+
+
+def test_device_resident_attribute_directions(golden_dir):
+    """tools/utils_attr.py:124-207 on the GPU: activations streamed batch by batch into running sums,
+    against the reference's own result (golden) and the oracle; then the files drive the write hook."""
+    import os
+    import tempfile
+    from oracle import attr_oracle as A
+    from uspace_amd.tools.utils_attr import DirectionAccumulator
+    z = np.load(os.path.join(golden_dir, "attr_directions.npz"))
+    for tag, adim in (("celeba", 40), ("ffhq", 11)):
+        attrs, feats, want = z[f"{tag}_attrs"], z[f"{tag}_feats"], z[f"{tag}_delta"]
+        acc = DirectionAccumulator(adim)
+        N, T = feats.shape[:2]
+        for lo in range(0, N, 10):                     # ragged last batch (37 = 10+10+10+7)
+            for ti in range(T):
+                acc.update(f"0.{ti}0", torch.from_numpy(feats[lo:lo + 10, ti]).cuda(), attrs[lo:lo + 10])
+        with tempfile.TemporaryDirectory() as d:
+            ts = acc.finalize(d)
+            assert ts == ["0.00", "0.10", "0.20"]
+            for ti, t in enumerate(ts):
+                got = np.load(os.path.join(d, f"delta_{t}.npy"))
+                assert got.shape == want[:, ti].shape and got.dtype == np.float32
+                np.testing.assert_allclose(got, want[:, ti], rtol=2e-5, atol=2e-6, equal_nan=True)
+                np.testing.assert_allclose(got, A.delta_directions(attrs, feats[:, ti]), rtol=2e-5, atol=2e-6, equal_nan=True)
+    with pytest.raises(ValueError):
+        DirectionAccumulator(7)
+
+
+def test_read_hook_feeds_accumulator_then_write_hook_uses_it(golden_dir):
+    """README workflow on the device: encode with the read hook (mid block) accumulating directions, finalize,
+    then decode with the write hook reading those files."""
+    import os
+    import tempfile
+    from uspace_amd.flow_matching import CNF
+    from uspace_amd.tools.utils_attr import DirectionAccumulator
+    from uspace_amd.tools.utils_uvit import get_nnet
+    z, sd = load_sd(golden_dir, "tiny_u.npz")
+    net = get_nnet("uvit", num_classes=-1, **TINY)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.cuda().eval()
+    cnf = CNF(net)
+    rng = np.random.default_rng(0)
+    attrs = (rng.random((3, 40)) < 0.5).astype(np.int64)
+    attrs[:, 5] = [1, 0, 1]
+    x0 = torch.from_numpy(z["x"]).cuda()
+    acc = DirectionAccumulator(40)
+    sk = _solver_kwargs(solver_fix_step=0.25)
+    cnf.encode(x0, None, dissect_task="uspace_uvit", dissect_name="read", edit_loc="mid", read_path_root="/unused",
+               batch_id=0, direction_accumulator=acc, attrs=attrs, solver_kwargs=sk)
+    with tempfile.TemporaryDirectory() as d:
+        ts = acc.finalize(d)
+        assert ts == ["0.25", "0.50", "0.75", "1.00"]
+        delta = np.load(os.path.join(d, "delta_0.25.npy"))
+        assert delta.shape == (40, 65, 64) and np.isfinite(delta[5]).all()
+        kw = dict(dissect_task="uspace_uvit", dissect_name="write_attr", t_edit=0.5, write_path_root=d, edit_loc="mid",
+                  ith_attr=5, solver_kwargs=sk)
+        edited = cnf.decode(x0, None, write_scale=2.0, **kw)
+        plain = cnf.decode(x0, None, write_scale=0.0, **kw)
+        assert bool(torch.isfinite(edited).all()) and rel_l2(edited.cpu().numpy(), plain.cpu().numpy()) > 1e-4

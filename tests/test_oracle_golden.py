@@ -123,3 +123,14 @@ def test_p2p_cases(golden_dir):
     for i in (4, 6, 7):
         np.testing.assert_allclose(outs[i], plain, rtol=1e-4, atol=1e-5)
     assert np.abs(outs[0] - plain).max() > 1e-4
+
+
+def test_attribute_directions_match_reference(golden_dir):
+    from oracle import attr_oracle as A
+    z = np.load(os.path.join(golden_dir, "attr_directions.npz"))
+    for tag in ("celeba", "ffhq"):
+        got = A.delta_directions(z[f"{tag}_attrs"], z[f"{tag}_feats"])
+        np.testing.assert_allclose(got, z[f"{tag}_delta"], rtol=1e-5, atol=1e-6, equal_nan=True)
+        assert np.isnan(got[1]).all()                 # attribute 1 has no negative example
+    with pytest.raises(ValueError):
+        A.delta_directions(np.zeros((4, 7), np.int64), np.zeros((4, 2), np.float32))

@@ -47,6 +47,7 @@ SIGNATURES = {
     "uspace_add_broadcast": (_I, [_P, _P, _P, _F, _I, _L, _P]),
     "uspace_add_broadcast_rows": (_I, [_P, _P, _P, _F, _P, _I, _L, _P]),
     "uspace_cast_f32_bf16": (_I, [_P, _P, _L, _P]),
+    "uspace_direction_accumulate": (_I, [_P, _P, _P, _P, _I, _L, _I, _P]),
     "uspace_ode_combine": (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _L, _P]),
     "uspace_ode_error_norm": (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _F, _F, _L, _P, _P, _P]),
     "uspace_uvit_num_params": (_I, [ctypes.POINTER(UvitConfig)]),

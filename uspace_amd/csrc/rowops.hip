@@ -259,6 +259,40 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src
     if (blockIdx.x == 0 && threadIdx.x < (n - rem0)) dst[rem0 + threadIdx.x] = f2bf(src[rem0 + threadIdx.x]);
 }
 
+// Attribute-direction statistics (reference: tools/utils_attr.py:124-145, done there in numpy over
+// activations staged through disk): pos[a, f] += sum_n [attr[n,a] == 1] feat[n, f], neg likewise for == 0.
+// One thread owns 4 consecutive features for ALL attributes: the batch column is read once into registers
+// (chunks of NB samples), the accumulators are read-modify-written once per call.  HBM-bound on the
+// accumulators: 2 * A * F * 8 bytes per call.
+template <int NB>
+__global__ __launch_bounds__(256) void direction_accum_kernel(const float* __restrict__ feat, const int* __restrict__ attr,
+                                                              float* __restrict__ pos, float* __restrict__ neg,
+                                                              int B, long F4, int A) {
+    const long f4 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f4 >= F4) return;
+    for (int n0 = 0; n0 < B; n0 += NB) {
+        f32x4 v[NB];
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+            v[n] = (n0 + n < B) ? ((const f32x4*)feat)[(long)(n0 + n) * F4 + f4] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < A; ++a) {
+            f32x4 p = (f32x4){0.f, 0.f, 0.f, 0.f}, q = p;
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                if (n0 + n < B) {
+                    const int t = attr[(long)(n0 + n) * A + a];      // wave-uniform: scalar load
+                    if (t == 1) p += v[n];
+                    else if (t == 0) q += v[n];
+                }
+            }
+            f32x4* pp = (f32x4*)pos + (long)a * F4 + f4;
+            f32x4* qq = (f32x4*)neg + (long)a * F4 + f4;
+            *pp += p;
+            *qq += q;
+        }
+    }
+}
+
 struct KPtrs {
     const float* k[8];
     float c[8];
@@ -385,6 +419,16 @@ extern "C" int uspace_add_broadcast_rows(float* x, uint16_t* x_bf16, const float
         hipLaunchKernelGGL(add_bcast_tail_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, x_bf16, delta, scale,
                            row_scale, per_sample, total);
     }
+    US_CHECK_LAUNCH();
+    return USPACE_OK;
+}
+
+extern "C" int uspace_direction_accumulate(const float* feat, const int* attr, float* pos_sum, float* neg_sum,
+                                           int B, long F, int A, uspace_stream_t stream) {
+    if (!feat || !attr || !pos_sum || !neg_sum || B <= 0 || F <= 0 || A <= 0 || (F & 3)) return USPACE_ERR_ARG;
+    const long F4 = F >> 2;
+    hipLaunchKernelGGL(direction_accum_kernel<16>, dim3((unsigned)((F4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       feat, attr, pos_sum, neg_sum, B, F4, A);
     US_CHECK_LAUNCH();
     return USPACE_OK;
 }

@@ -102,7 +102,15 @@ class DeltaCache:
         return hit
 
 
-def save_activation(path, tensor):
-    """read mode: np.save(f"{batch_id}_{t:.2f}", x) (libs/dissection.py:126-136)."""
+def save_activation(path, tensor, kwargs=None):
+    """read mode: np.save(f"{batch_id}_{t:.2f}", x) (libs/dissection.py:126-136).
+
+    Extension: with ``direction_accumulator=`` (tools.utils_attr.DirectionAccumulator) and ``attrs=``
+    ([B, attr_dim]) in the kwargs the activation is folded into device-resident attribute sums instead of
+    being written to disk (the file name's timestep part is the accumulator key)."""
+    acc = kwargs.get("direction_accumulator") if kwargs else None
+    if acc is not None:
+        acc.update(os.path.basename(path).split("_")[-1], tensor, kwargs["attrs"])
+        return
     os.makedirs(os.path.dirname(path), exist_ok=True)
     np.save(path, tensor.detach().cpu().numpy())

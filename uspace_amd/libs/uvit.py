@@ -72,7 +72,7 @@ class UViT(UViTBase):
             rows = torch.from_numpy(plan.row_scales).to(dev)
         if plan is not None and edit_loc == "head":
             if plan.kind == "read":
-                dissection.save_activation(plan.path, x)
+                dissection.save_activation(plan.path, x, kwargs)
             else:
                 delta = self._deltas().get(plan.path, plan.ith, dev, x[0].numel())
                 x = _hip.add_broadcast(x.detach().to(torch.float32).clone(), delta, plan.scale, row_scale=rows)
@@ -85,10 +85,10 @@ class UViT(UViTBase):
         out = self._run(x, timesteps, context=label_tok, mid_delta=mid_delta, mid_scale=mid_scale, mid_tap=mid_tap,
                         mid_row_scale=rows if mid_delta is not None else None)
         if mid_tap is not None:
-            dissection.save_activation(plan.path, mid_tap)
+            dissection.save_activation(plan.path, mid_tap, kwargs)
         if plan is not None and edit_loc == "tail":
             if plan.kind == "read":
-                dissection.save_activation(plan.path, out)
+                dissection.save_activation(plan.path, out, kwargs)
             else:
                 delta = self._deltas().get(plan.path, plan.ith, dev, out[0].numel())
                 out = _hip.add_broadcast(out, delta, plan.scale, row_scale=rows)
