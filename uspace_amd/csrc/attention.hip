@@ -35,8 +35,9 @@ __host__ __device__ constexpr int vt_stride_bytes(int keys) {
 // NT = number of 16-key tiles the kernel is compiled for (keys beyond L are masked).
 // LC > 0: the sequence length is a compile-time constant (the production lengths 257 and 334), so
 // the tail-tile masks, the tile-skip tests and the V^T stride fold away; LC == 0: generic length.
-template <int NT, int LC, bool SCALED>
-__global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restrict__ qkv,
+// NW = waves per workgroup: 4 when two workgroups fit a CU's LDS (L <= 272), 8 when only one does.
+template <int NT, int LC, bool SCALED, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void attention_kernel(const bf16_t* __restrict__ qkv,
                                                            const float* __restrict__ key_scale,
                                                            bf16_t* __restrict__ out, int L_rt, int H, int vt_stride_rt) {
     const int L = LC > 0 ? LC : L_rt;
@@ -65,8 +66,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
     {
         const int r8 = lane >> 3, cpos = lane & 7;
 #pragma unroll
-        for (int blk = 0; blk < (KROWS / 8 + 3) / 4; ++blk) {
-            const int rb = (blk * 4 + wave) * 8;                   // first row of this wave's 8-row block
+        for (int blk = 0; blk < (KROWS / 8 + NW - 1) / NW; ++blk) {
+            const int rb = (blk * NW + wave) * 8;                   // first row of this wave's 8-row block
             if (rb < KROWS) {
                 const int r = rb + r8;
                 const int c = cpos ^ ((r >> 1) & 7);
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
     }
     // ---- stage V transposed: lane <-> key, so each ds_write_b16 of a wave covers 64 consecutive keys
 #pragma unroll 1
-    for (int key0 = wave * 64; key0 < KEYS; key0 += 256) {
+    for (int key0 = wave * 64; key0 < KEYS; key0 += 64 * NW) {
         const int key = key0 + lane;
         if (key < KEYS) {
             uint4 v[8];
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
         }
     }
     if constexpr (SCALED) {
-        for (int k = tid; k < KROWS; k += 256) sKs[k] = k < L ? key_scale[(size_t)b * L + k] : 0.f;
+        for (int k = tid; k < KROWS; k += 64 * NW) sKs[k] = k < L ? key_scale[(size_t)b * L + k] : 0.f;
     }
 
     const int fr = lane & 15;
@@ -122,9 +123,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
     __syncthreads();   // (drains the LDS-DMA queue) K, V^T, key scales visible
 
 #pragma unroll 1
-    for (int qt = wave; qt < n_qt; qt += 4) {
+    for (int qt = wave; qt < n_qt; qt += NW) {
         const int q0 = qt * 16;
-        load_q(qt + 4 < n_qt ? qt + 4 : qt, qn);       // prefetch the next tile's Q fragment
+        load_q(qt + NW < n_qt ? qt + NW : qt, qn);       // prefetch the next tile's Q fragment
         // the K fragments are the same for every query tile: stop the compiler from hoisting all
         // 2*NT of them out of this loop (136+ VGPRs -> scratch spills); LDS re-reads are the point
         int lds_k = 0;
@@ -224,26 +225,28 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
     }
 }
 
-template <int NT, int LC, bool SCALED>
+template <int NT, int LC, bool SCALED, int NW>
 int launch_attn2(const bf16_t* qkv, const float* ks, bf16_t* out, int B, int L, int H, hipStream_t s) {
     constexpr int NP = (NT + 1) / 2;
     const int vts = vt_stride_bytes(NP * 32);
     const size_t lds = (size_t)NT * 16 * KROW_BYTES + (size_t)DH * vts + (SCALED ? NT * 16 * 4 : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)attention_kernel<NT, LC, SCALED>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)attention_kernel<NT, LC, SCALED, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess)
             return USPACE_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((attention_kernel<NT, LC, SCALED>), dim3(B * H), dim3(256), lds, s, qkv, ks, out, L, H, vts);
+    hipLaunchKernelGGL((attention_kernel<NT, LC, SCALED, NW>), dim3(B * H), dim3(64 * NW), lds, s, qkv, ks, out, L, H, vts);
     US_CHECK_LAUNCH();
     return USPACE_OK;
 }
 
 template <int NT, int LC>
 int launch_attn(const bf16_t* qkv, const float* ks, bf16_t* out, int B, int L, int H, hipStream_t s) {
-    return ks ? launch_attn2<NT, LC, true>(qkv, ks, out, B, L, H, s) : launch_attn2<NT, LC, false>(qkv, ks, out, B, L, H, s);
+    constexpr int NW = NT > 17 ? 8 : 4;     // > 80 KB of LDS per workgroup: one workgroup per CU, so give it 8 waves
+    return ks ? launch_attn2<NT, LC, true, NW>(qkv, ks, out, B, L, H, s)
+              : launch_attn2<NT, LC, false, NW>(qkv, ks, out, B, L, H, s);
 }
 
 }  // namespace
