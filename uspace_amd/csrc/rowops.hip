@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ im
         for (int d = threadIdx.x * 4; d < D; d += blockDim.x * 4) put4(d, *(const f32x4*)(src + d));
     } else {
         // PatchEmbed conv k = s = p (libs/uvit.py:171-178): pixels consumed in (c, i, j) order
-        __shared__ float px[64];
+        __shared__ __attribute__((aligned(16))) float px[64];
         const int tpatch = l - (1 + n_extra);
         const int ph = tpatch / g, pwid = tpatch % g;
         const int npx = C * p * p;
@@ -114,12 +114,26 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ im
         __syncthreads();
         for (int d = threadIdx.x * 4; d < D; d += blockDim.x * 4) {
             f32x4 v = *(const f32x4*)(pb + d);
+            if ((npx & 3) == 0) {            // 16-byte weight loads (npx = 16 in every reference config)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float* w = pw + (size_t)(d + e) * npx;
-                float s = v[e];
-                for (int q = 0; q < npx; ++q) s += w[q] * px[q];
-                v[e] = s;
+                for (int e = 0; e < 4; ++e) {
+                    const f32x4* w4 = (const f32x4*)(pw + (size_t)(d + e) * npx);
+                    float s = v[e];
+                    for (int q = 0; q < npx / 4; ++q) {
+                        const f32x4 w = w4[q];
+                        const f32x4 x4 = *(const f32x4*)(px + 4 * q);
+                        s += (w[0] * x4[0] + w[1] * x4[1]) + (w[2] * x4[2] + w[3] * x4[3]);
+                    }
+                    v[e] = s;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float* w = pw + (size_t)(d + e) * npx;
+                    float s = v[e];
+                    for (int q = 0; q < npx; ++q) s += w[q] * px[q];
+                    v[e] = s;
+                }
             }
             put4(d, v);
         }
