@@ -54,6 +54,10 @@ def lib():
     L.oracle_timestep_embedding.argtypes = [f32p, f32p, lg, lg]
     L.oracle_unpatchify.argtypes = [f32p, f32p, lg, lg, lg, lg]
     L.oracle_conv3x3.argtypes = [f32p, f32p, f32p, f32p, lg, lg, lg]
+    L.oracle_conv2d.argtypes = [f32p, f32p, f32p, f32p, lg, lg, lg, lg, lg, lg]
+    L.oracle_groupnorm.argtypes = [f32p, f32p, f32p, f32p, lg, lg, lg, lg, ctypes.c_float]
+    L.oracle_conv2d.restype = None
+    L.oracle_groupnorm.restype = None
     for n in ("oracle_linear", "oracle_layernorm", "oracle_gelu", "oracle_attention", "oracle_patch_embed",
               "oracle_timestep_embedding", "oracle_unpatchify", "oracle_conv3x3", "oracle_set_threads"):
         getattr(L, n).restype = None
@@ -142,4 +146,22 @@ def conv3x3(x, w, b):
     B, C, HW, _ = x.shape
     out = np.empty_like(x)
     lib().oracle_conv3x3(_p(x), _p(_f32(w)), _p(_f32(b)), _p(out), B, C, HW)
+    return out
+
+
+def conv2d(x, w, b):
+    x = _f32(x)
+    w = _f32(w)
+    B, Ci, H, W = x.shape
+    Co, _, k, _ = w.shape
+    out = np.empty((B, Co, H, W), np.float32)
+    lib().oracle_conv2d(_p(x), _p(w), _p(_f32(b)) if b is not None else None, _p(out), B, Ci, Co, H, W, k)
+    return out
+
+
+def groupnorm(x, g, b, groups=32, eps=1e-6):
+    x = _f32(x)
+    B, C = x.shape[:2]
+    out = np.empty_like(x)
+    lib().oracle_groupnorm(_p(x), _p(_f32(g)), _p(_f32(b)), _p(out), B, C, x.size // (B * C), groups, eps)
     return out

@@ -18,6 +18,7 @@ What is pinned:
                                     own reader raises EinopsError on [n,L,D] deltas)
   p2p_t2i                           tools/utils_t2i.py:265 attention-map hook
   attr_directions                   tools/utils_attr.py:124 mean(pos) - mean(neg) attribute directions
+  vae_decoder_tiny                  libs/autoencoder.py:303-409,446-450 SD-VAE decoder, tiny config + taps
   big_{S,L}_{u,t}                   seed-regenerated weights (sha256 pinned) -> out, B=2
   euler20_S_u                       BASELINE config 1: 20 fixed Euler steps, B=4, driven by
                                     a plain loop written here around the reference nnet
@@ -392,6 +393,44 @@ def make_attr_directions():
     save("attr_directions.npz", **out)
 
 
+def make_vae_decoder():
+    """libs/autoencoder.py:303-409 Decoder + :446-450 decode (post_quant_conv, 1/scale_factor) at a tiny
+    configuration (ch=64, ch_mult (1,2), 1 res block, z 8x8 -> image 16x16), seeded default init."""
+    import importlib
+    ae = importlib.import_module("libs.autoencoder")
+    dd = dict(double_z=True, z_channels=4, resolution=16, in_channels=3, out_ch=3, ch=64, ch_mult=[1, 2],
+              num_res_blocks=1, attn_resolutions=[], dropout=0.0)
+    torch.manual_seed(WEIGHT_SEED + 7)
+    dec = ae.Decoder(**dd).eval()
+    pq = torch.nn.Conv2d(4, 4, 1)
+    g = torch.Generator().manual_seed(INPUT_SEED)
+    z = torch.randn(3, 4, 8, 8, generator=g) * 0.18215
+    store = {}
+    hooks = []
+    for name, mod in (("conv_in", dec.conv_in), ("mid1", dec.mid.block_1), ("attn", dec.mid.attn_1),
+                      ("mid2", dec.mid.block_2), ("up1_b0", dec.up[1].block[0]), ("up1_b1", dec.up[1].block[1]),
+                      ("up1_us", dec.up[1].upsample), ("up0_b0", dec.up[0].block[0]), ("up0_b1", dec.up[0].block[1]),
+                      ("norm_out", dec.norm_out)):
+        hooks.append(mod.register_forward_hook(lambda _m, _a, o, n=name: store.__setitem__(n, o.detach().numpy().copy())))
+    with torch.no_grad():
+        img = dec(pq(z * (1.0 / 0.18215)))
+    for h in hooks:
+        h.remove()
+    # weights are NOT stored (5 MB): the product module's seeded init replays the same RNG consumption
+    # (Decoder first, then post_quant_conv); the sha256 of the state_dict pins bit-equality
+    h = hashlib.sha256()
+    full = {f"decoder.{k}": v for k, v in dec.state_dict().items()}
+    full.update({f"post_quant_conv.{k}": v for k, v in pq.state_dict().items()})
+    for k, v in full.items():
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(v.detach().numpy()).tobytes())
+    meta = dict(ddconfig=dd, weight_seed=WEIGHT_SEED + 7, sha256=h.hexdigest(), keys=list(full.keys()),
+                scale_factor=0.18215, n_params=int(sum(v.numel() for v in full.values())))
+    out = {f"tap/{k}": store[k] for k in ("conv_in", "attn", "up1_us", "up0_b0", "norm_out")}
+    out.update(z=z.numpy(), img=img.numpy(), meta_json=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
+    save("vae_decoder_tiny.npz", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-large", action="store_true")
@@ -404,6 +443,7 @@ def main():
     mt, xt, ctx = make_tiny_t2i(uvit_t2i)
     make_p2p_t2i(mt, xt, ctx)
     make_attr_directions()
+    make_vae_decoder()
     if not args.skip_large:
         timing = dict(threads=torch.get_num_threads(), nproc=os.cpu_count(),
                       cpu=[l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0],

@@ -134,3 +134,21 @@ def test_attribute_directions_match_reference(golden_dir):
         assert np.isnan(got[1]).all()                 # attribute 1 has no negative example
     with pytest.raises(ValueError):
         A.delta_directions(np.zeros((4, 7), np.int64), np.zeros((4, 2), np.float32))
+
+
+def test_vae_decoder_oracle_matches_reference(golden_dir):
+    import json
+    import torch
+    from oracle import vae_oracle as V
+    from uspace_amd.libs.autoencoder import FrozenAutoencoderKL
+    z = np.load(os.path.join(golden_dir, "vae_decoder_tiny.npz"))
+    meta = json.loads(bytes(z["meta_json"]).decode())
+    torch.manual_seed(meta["weight_seed"])
+    m = FrozenAutoencoderKL(meta["ddconfig"], 4)
+    sd = {k: v.numpy() for k, v in m.state_dict().items()}
+    assert list(sd.keys()) == meta["keys"]
+    taps = {}
+    img = V.decode(sd, z["z"], meta["ddconfig"]["ch_mult"], meta["ddconfig"]["num_res_blocks"], taps=taps)
+    for k in [f for f in z.files if f.startswith("tap/")]:
+        np.testing.assert_allclose(taps[k[4:]], z[k], rtol=2e-4, atol=2e-5, err_msg=k)
+    np.testing.assert_allclose(img, z["img"], rtol=2e-4, atol=2e-5)

@@ -430,13 +430,47 @@ int launch(const GemmArgs& a, hipStream_t s, int wg_per_round) {
     return USPACE_OK;
 }
 
+// Rows are independent, so one GEMM may be issued as two launches over disjoint row ranges.
+inline GemmArgs row_slice(const GemmArgs& a, int m_lo, int m_hi) {
+    GemmArgs g = a;
+    g.M = m_hi - m_lo;
+    g.A = a.A + (size_t)m_lo * a.lda;
+    if (a.A2) g.A2 = a.A2 + (size_t)m_lo * a.lda2;
+    if (a.resid) g.resid = a.resid + (size_t)m_lo * a.ld_resid;
+    if (a.out_f32) g.out_f32 = a.out_f32 + (size_t)m_lo * a.ld_f32;
+    if (a.out_bf16) g.out_bf16 = a.out_bf16 + (size_t)m_lo * a.ld_bf16;
+    return g;
+}
+
 template <int FLAGS>
 int dispatch_tile(const GemmArgs& a, hipStream_t s) {
     // 256x256 tiles (8 waves, ~130 KiB LDS, 1 workgroup/CU) when they fill the 256 CUs at least
     // once; otherwise 128x128 tiles (4 waves, ~66 KiB LDS, 2 workgroups/CU).
-    const long big_tiles = (long)(a.M / 256) * us_cdiv(a.N, 256);
-    if (big_tiles >= 256) return launch<256, 256, 2, 4, FLAGS>(a, s, 256);
-    return launch<128, 128, 2, 2, FLAGS>(a, s, 512);
+    const int tn = us_cdiv(a.N, 256);
+    const long big_tiles = (long)(a.M / 256) * tn;
+    if (big_tiles < 256) return launch<128, 128, 2, 2, FLAGS>(a, s, 512);
+    // Wave quantisation: when the last round of 256x256 tiles would be mostly empty (e.g. T2I, M = 64*334,
+    // N = 1024: 320 tiles = 1.25 rounds), run whole rounds with big tiles and the remaining rows as one
+    // round of 128x128 tiles (2 per CU, ~0.55 of a big round) -- rows are independent, so it is two launches.
+    const Plan p = plan_rows(a.M, 256, tn, 256);
+    const int rounds = us_cdiv(p.tiles_m * tn, 256);
+    const double single = rounds * (p.xrows > 0 ? 1.0625 : 1.0);
+    const int full_rounds = (int)(big_tiles / 256);
+    if (full_rounds >= 1 && tn <= 256) {
+        const int tm_full = full_rounds * 256 / tn;                  // tile rows that fill whole rounds
+        const int m1 = tm_full * 256;
+        const int rest = a.M - m1;
+        if (rest > 0 && tm_full * tn == full_rounds * 256) {
+            const long small_tiles = (long)us_cdiv(rest, 128) * us_cdiv(a.N, 128);
+            const double split = full_rounds + 0.55 * (double)us_cdiv((int)small_tiles, 512) + 0.06;
+            if (small_tiles <= 512 && split < single - 0.05) {
+                int rc = launch<256, 256, 2, 4, FLAGS>(row_slice(a, 0, m1), s, 256);
+                if (rc != USPACE_OK) return rc;
+                return launch<128, 128, 2, 2, FLAGS>(row_slice(a, m1, a.M), s, 512);
+            }
+        }
+    }
+    return launch<256, 256, 2, 4, FLAGS>(a, s, 256);
 }
 
 }  // namespace

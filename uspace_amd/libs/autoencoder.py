@@ -1,0 +1,148 @@
+"""Decode-side drop-in for the reference's frozen SD KL-VAE (libs/autoencoder.py:303-409 ``Decoder``,
+:412-450 ``FrozenAutoencoderKL.decode``): latents [B,4,32,32] -> images [B,3,256,256].
+
+Same ``state_dict`` keys as the reference for ``decoder.*`` and ``post_quant_conv.*`` (the encoder half of a
+checkpoint is accepted and ignored).  The arithmetic runs in libuspace_hip.so: 3x3 convolutions as 9-slab
+bf16 MFMA GEMMs over a zero-bordered NHWC layout, GroupNorm+SiLU, nearest upsampling and the single-head
+mid-block attention as HIP kernels; no torch compute.  SURVEY.md 8(f) rank 1.
+"""
+import ctypes
+import json
+
+import torch
+import torch.nn as nn
+
+from .. import _hip
+from ._uvit_core import ParamGroup
+
+
+def _conv(group, name, cout, cin, k):
+    c = group.child(name)
+    c.add("weight", cout, cin, k, k)
+    c.add("bias", cout)
+    return c
+
+
+def _norm(group, name, ch):
+    n = group.child(name)
+    n.add("weight", ch)
+    n.add("bias", ch)
+    return n
+
+
+def _resblock(cin, cout):
+    b = ParamGroup()
+    _norm(b, "norm1", cin)
+    _conv(b, "conv1", cout, cin, 3)
+    _norm(b, "norm2", cout)
+    _conv(b, "conv2", cout, cout, 3)
+    if cin != cout:
+        _conv(b, "nin_shortcut", cout, cin, 1)
+    b.cin, b.cout = cin, cout
+    return b
+
+
+class FrozenAutoencoderKL(nn.Module):
+    def __init__(self, ddconfig, embed_dim=4, pretrained_path=None, scale_factor=0.18215):
+        super().__init__()
+        dd = dict(ddconfig)
+        if dd.get("attn_resolutions"):
+            raise NotImplementedError("attention inside the up path is not used by the reference (attn_resolutions=[])")
+        if dd.get("give_pre_end") or dd.get("tanh_out") or dd.get("use_linear_attn") or dd.get("resamp_with_conv") is False:
+            raise NotImplementedError("non-default Decoder options")
+        self.ch, self.ch_mult = dd["ch"], tuple(dd["ch_mult"])
+        self.num_res_blocks, self.resolution = dd["num_res_blocks"], dd["resolution"]
+        self.z_channels, self.out_ch = dd["z_channels"], dd["out_ch"]
+        if embed_dim != self.z_channels or self.z_channels != 4 or self.out_ch != 3:
+            raise NotImplementedError("embed_dim == z_channels == 4 and out_ch == 3 (the SD VAE the reference uses)")
+        if self.ch % 64:
+            raise NotImplementedError("ch must be a multiple of 64 (128 in the reference)")
+        self.embed_dim, self.scale_factor = embed_dim, scale_factor
+        nres = len(self.ch_mult)
+        self.z_res = self.resolution // 2 ** (nres - 1)
+        block_in = self.ch * self.ch_mult[-1]
+
+        dec = ParamGroup()
+        _conv(dec, "conv_in", block_in, self.z_channels, 3)
+        mid = dec.child("mid")
+        mid.add_module("block_1", _resblock(block_in, block_in))
+        attn = mid.child("attn_1")
+        _norm(attn, "norm", block_in)
+        for n in ("q", "k", "v", "proj_out"):
+            _conv(attn, n, block_in, block_in, 1)
+        mid.add_module("block_2", _resblock(block_in, block_in))
+        ups = [None] * nres
+        for lvl in reversed(range(nres)):                       # construction order of the reference
+            up = ParamGroup()
+            block_out = self.ch * self.ch_mult[lvl]
+            blocks = []
+            for _ in range(self.num_res_blocks + 1):
+                blocks.append(_resblock(block_in, block_out))
+                block_in = block_out
+            up.add_module("block", nn.ModuleList(blocks))
+            up.add_module("attn", nn.ModuleList())
+            if lvl != 0:
+                _conv(up.child("upsample"), "conv", block_in, block_in, 3)
+            ups[lvl] = up
+        dec.add_module("up", nn.ModuleList(ups))
+        _norm(dec, "norm_out", block_in)
+        _conv(dec, "conv_out", self.out_ch, block_in, 3)
+        self.decoder = dec
+        self.post_quant_conv = ParamGroup()
+        self.post_quant_conv.add("weight", self.z_channels, embed_dim, 1, 1)
+        self.post_quant_conv.add("bias", self.z_channels)
+        self._reference_init_()
+        self._packed = None
+        self._ws = {}
+        if pretrained_path is not None:
+            self.load_state_dict(torch.load(pretrained_path, map_location="cpu"))
+        self.eval()
+        self.requires_grad_(False)
+
+    # ------------------------------------------------------------------ init / checkpoints
+    def _conv_modules_in_construction_order(self):
+        d = self.decoder
+        yield d.conv_in
+        for blk in (d.mid.block_1,):
+            yield from self._block_convs(blk)
+        a = d.mid.attn_1
+        yield from (a.q, a.k, a.v, a.proj_out)
+        yield from self._block_convs(d.mid.block_2)
+        for lvl in reversed(range(len(self.ch_mult))):
+            for blk in d.up[lvl].block:
+                yield from self._block_convs(blk)
+            if lvl != 0:
+                yield d.up[lvl].upsample.conv
+        yield d.conv_out
+        yield self.post_quant_conv
+
+    @staticmethod
+    def _block_convs(blk):
+        yield blk.conv1
+        yield blk.conv2
+        if hasattr(blk, "nin_shortcut"):
+            yield blk.nin_shortcut
+
+    @torch.no_grad()
+    def _reference_init_(self):
+        """torch's default Conv2d init in the reference's construction order (Decoder, then post_quant_conv),
+        so the same ``torch.manual_seed`` yields the same weights; GroupNorm affine = (1, 0)."""
+        for c in self._conv_modules_in_construction_order():
+            cout, cin, k, _ = c.weight.shape
+            ref = nn.Conv2d(cin, cout, k, padding=k // 2)
+            c.weight.copy_(ref.weight)
+            c.bias.copy_(ref.bias)
+        for name, p in self.named_parameters():
+            if ".norm" in name or name.endswith("norm.weight") or name.endswith("norm.bias"):
+                if p.dim() == 1 and ("norm" in name.split(".")[-2]):
+                    p.fill_(1.0 if name.endswith("weight") else 0.0)
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Accepts a full autoencoder checkpoint: ``encoder.*`` / ``quant_conv.*`` entries are ignored."""
+        sd = {k: v for k, v in state_dict.items() if not (k.startswith("encoder.") or k.startswith("quant_conv."))}
+        return super().load_state_dict(sd, strict=strict)
+
+    def forward(self, inputs, fn):
+        if fn == "decode":
+            return self.decode(inputs)
+        raise NotImplementedError(f"{fn}: only the decode side is implemented on the MI355X path")
