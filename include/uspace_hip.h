@@ -48,8 +48,8 @@ USPACE_API int uspace_abi_version(void);
 
 /* nn.Linear on bf16 operands with fp32 accumulation on the MFMA cores:
  *     acc[M,N] = [A | A2][M,K] . W[N,K]^T
- * A is [M,K1] (row stride lda), A2 (optional, may be NULL when K1 == K) is [M,K-K1]
- * (row stride lda2, which must equal lda): the two K-slabs of skip_linear(cat([x, skip])) without materialising
+ * A is [M,K1] (row stride lda), A2 (optional, NULL when K1 == K) is [M,K1] with K == 2*K1, K1 a power
+ * of two (row stride lda2, which must equal lda): the two K-slabs of skip_linear(cat([x, skip])) without materialising
  * the concat (libs/uvit.py:159).  W is nn.Linear's own [out,in] layout (row stride ldw).
  * K1 and K must be multiples of 64, N a multiple of 4.  resid_in and out_f32 may alias
  * (x += ...; libs/uvit.py:160-161).  Replaces libs/uvit.py:89,116,159; libs/timm.py:107-110;
@@ -59,6 +59,17 @@ USPACE_API int uspace_gemm_bf16(const uint16_t* A, int lda, const uint16_t* A2, 
                      const float* bias, const float* resid_in, int ld_resid,
                      float* out_f32, int ld_f32, uint16_t* out_bf16, int ld_bf16,
                      uspace_stream_t stream);
+
+/* Sum of row-shifted GEMMs:  acc[m, n] = sum_t A[m + row_shift[t], 0:K1] . W[n, t*K1:(t+1)*K1]  (+ epilogue
+ * as above).  With rows = pixels of a zero-bordered NHWC map [B, H+2, W+2, C] and the 9 shifts
+ * dy*(W+2)+dx this is Conv2d(C, N, 3, padding=1) (libs/autoencoder.py:85-112); the caller provides
+ * (W+3) guard rows before and after the map (border outputs are garbage and must be re-zeroed by the
+ * consumer).  K1 a power of two >= 64, n_slab <= 9, W rows are [tap][K1] contiguous.  row_shift is a HOST
+ * array. */
+USPACE_API int uspace_gemm_slabs_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int N, int K1,
+                                      int n_slab, const int* row_shift, int epi_flags, const float* bias,
+                                      const float* resid_in, int ld_resid, float* out_f32, int ld_f32,
+                                      uint16_t* out_bf16, int ld_bf16, uspace_stream_t stream);
 
 /* nn.LayerNorm(D, eps) over fp32 rows -> bf16 rows (libs/uvit.py:135,139,160-161). D % 4 == 0. */
 USPACE_API int uspace_layernorm_f32_bf16(const float* x, const float* gamma, const float* beta, uint16_t* y,
@@ -178,6 +189,45 @@ typedef struct uspace_uvit_io {
 
 USPACE_API int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* blob, void* workspace,
                         size_t workspace_bytes, const uspace_uvit_io* io, int B, uspace_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * VAE decode (the step after the solve): FrozenAutoencoderKL.decode of libs/autoencoder.py:446-450 =
+ * z / scale_factor -> post_quant_conv -> Decoder.forward (libs/autoencoder.py:376-409).
+ * ------------------------------------------------------------------------------------- */
+typedef struct uspace_vae_config {
+    int ch;              /* 128 */
+    int ch_mult[4];      /* {1,2,4,4} */
+    int n_levels;        /* 4 */
+    int num_res_blocks;  /* 2 */
+    int resolution;      /* 256 (output); latents are resolution >> (n_levels-1) */
+} uspace_vae_config;
+
+/* GroupNorm(32 groups, C, eps) (+ x*sigmoid(x) when silu != 0) over a zero-bordered NHWC fp32 map
+ * [B, H+2, H+2, C] -> bf16 operand map of the same geometry with the border rows zeroed
+ * (libs/autoencoder.py:26-32).  C a power of two in [64, 512]; stats_scratch: device float[B*65*64].
+ * Deterministic (no atomics): repeated calls give bit-identical results. */
+USPACE_API int uspace_groupnorm_map_bf16(const float* x, const float* gamma, const float* beta, uint16_t* y,
+                                         float* stats_scratch, int B, int H, int C, int silu, float eps,
+                                         uspace_stream_t stream);
+
+/* parameter tensors in the reference's state_dict order: decoder.* then post_quant_conv.* */
+USPACE_API int uspace_vae_num_params(const uspace_vae_config* cfg);
+USPACE_API long uspace_vae_param_numel(const uspace_vae_config* cfg, int index);
+USPACE_API size_t uspace_vae_weight_bytes(const uspace_vae_config* cfg);
+USPACE_API size_t uspace_vae_workspace_bytes(const uspace_vae_config* cfg, int B);
+USPACE_API int uspace_vae_pack_weights(const uspace_vae_config* cfg, const float* const* params, int n_params,
+                                       void* blob, size_t blob_bytes, uspace_stream_t stream);
+/* z [B,4,h,h] fp32 (NCHW) -> out [B,3,resolution,resolution] fp32 (NCHW).  B * (resolution+2)^2 * 512 must stay
+ * below 2^30 (decode in chunks, as the reference does: dissect_lfm.py:86-98). */
+USPACE_API int uspace_vae_decode(const uspace_vae_config* cfg, const void* blob, void* workspace, size_t workspace_bytes,
+                                 const float* z, float scale_factor, float* out, int B, uspace_stream_t stream);
+
+/* Test aid: stop after stage `stop_after` (0 conv_in, 1 mid.block_1, 2 mid.attn_1, 3 mid.block_2, then one per
+ * res block / upsample conv in execution order) and copy that fp32 zero-bordered NHWC map [B,H+2,H+2,C] to
+ * `dump` (device, large enough); hc_out (host int[2]) receives {H, C}. */
+USPACE_API int uspace_vae_decode_tap(const uspace_vae_config* cfg, const void* blob, void* workspace, size_t workspace_bytes,
+                                     const float* z, float scale_factor, int B, int stop_after, float* dump, int* hc_out,
+                                     uspace_stream_t stream);
 
 /* hipGraph form of the forward.  _create() runs the forward once eagerly on `capture_stream` (must be a
  * real, non-NULL stream), then captures the same launch sequence and instantiates it.  The pointers in

@@ -196,3 +196,57 @@ def test_ode_state_kernels(hip):
     tol = 1e-4 + 1e-3 * np.maximum(np.abs(y), np.abs(y1))
     want = np.sqrt(np.mean((err / tol) ** 2))
     assert abs(float(res.item()) - want) / want < 1e-4
+
+
+@pytest.mark.parametrize("B,Ci,Co,H", [(2, 64, 128, 8), (1, 128, 64, 16), (3, 256, 256, 12)])
+def test_conv3x3_as_nine_row_shifted_gemms(hip, B, Ci, Co, H):
+    """Conv2d(Ci, Co, 3, padding=1) == sum over the 9 taps of GEMMs on a zero-bordered NHWC map whose rows are
+    shifted by dy*(W+2)+dx (libs/autoencoder.py:85-112), checked on interior pixels against the oracle."""
+    rng = np.random.default_rng(Ci + Co + H)
+    W_ = H
+    x = bf16_round(_rand(rng, B, Ci, H, W_))
+    w = bf16_round(_rand(rng, Co, Ci, 3, 3) * 0.05)
+    b = _rand(rng, Co)
+    ref = C.conv2d(x, w, b)                                            # [B, Co, H, W]
+    P = W_ + 2
+    rows = B * (H + 2) * P
+    guard = P + 1
+    buf = torch.zeros(rows + 2 * guard, Ci, dtype=torch.bfloat16, device="cuda")
+    pad = torch.zeros(B, H + 2, P, Ci)
+    pad[:, 1:-1, 1:-1, :] = torch.from_numpy(x).permute(0, 2, 3, 1)
+    buf[guard:guard + rows] = pad.reshape(rows, Ci).to(torch.bfloat16).cuda()
+    A = buf[guard:guard + rows]
+    wk = torch.from_numpy(w).permute(0, 2, 3, 1).reshape(Co, 9 * Ci).contiguous().to(torch.bfloat16).cuda()   # [Co][tap][Ci]
+    shifts = [dy * P + dx for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+    out = torch.empty(rows, Co, dtype=torch.float32, device="cuda")
+    hip.gemm_slabs(A, wk, shifts, bias=to_dev(b), out_f32=out)
+    got = out.view(B, H + 2, P, Co)[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2).cpu().numpy()
+    assert rel_l2(got, ref) < 1e-5
+
+
+@pytest.mark.parametrize("B,C_,H,silu", [(2, 64, 16, 1), (3, 128, 8, 0), (1, 256, 12, 1), (2, 512, 8, 1)])
+def test_groupnorm_on_zero_bordered_map(hip, B, C_, H, silu):
+    """GroupNorm(32, C, eps=1e-6) (+SiLU) of libs/autoencoder.py:26-32 on the NHWC map layout of the VAE path."""
+    import ctypes
+    rng = np.random.default_rng(C_ + H)
+    x = (_rand(rng, B, C_, H, H, scale=2.0) + 0.5).astype(np.float32)
+    g = _rand(rng, C_) + 1.0
+    bt = _rand(rng, C_)
+    ref = C.groupnorm(x, g, bt, groups=32, eps=1e-6)
+    if silu:
+        ref = ref / (1.0 + np.exp(-ref))
+    pad = torch.full((B, H + 2, H + 2, C_), 7.0)                 # border holds garbage on purpose
+    pad[:, 1:-1, 1:-1, :] = torch.from_numpy(x).permute(0, 2, 3, 1)
+    xm = pad.contiguous().cuda()
+    y = torch.empty(B, H + 2, H + 2, C_, dtype=torch.bfloat16, device="cuda")
+    scratch = torch.empty(B * 65 * 64, device="cuda")
+    gd, bd = to_dev(g), to_dev(bt)
+    rc = hip.lib().uspace_groupnorm_map_bf16(hip.ptr(xm), hip.ptr(gd), hip.ptr(bd), hip.ptr(y), hip.ptr(scratch),
+                                             B, H, C_, silu, ctypes.c_float(1e-6), hip.stream_ptr())
+    assert rc == 0
+    yy = y.float().cpu()
+    got = yy[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2).numpy()
+    assert np.abs(got - ref).max() <= 2.0 ** -8 * np.abs(ref).max() * 1.5 + 2e-3
+    border = yy.clone()
+    border[:, 1:-1, 1:-1, :] = 0
+    assert float(border.abs().max()) == 0.0                       # zero border = the next conv's padding

@@ -34,12 +34,18 @@ class UvitIO(ctypes.Structure):
         ("mid_row_scale", ctypes.c_void_p)]
 
 
+class VaeConfig(ctypes.Structure):
+    _fields_ = [("ch", ctypes.c_int), ("ch_mult", ctypes.c_int * 4), ("n_levels", ctypes.c_int),
+                ("num_res_blocks", ctypes.c_int), ("resolution", ctypes.c_int)]
+
+
 _P, _I, _L, _F, _SZ = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
 
 # name -> (restype, argtypes); must list every symbol include/uspace_hip.h declares
 SIGNATURES = {
     "uspace_abi_version": (_I, []),
     "uspace_gemm_bf16": (_I, [_P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I, _P]),
+    "uspace_gemm_slabs_bf16": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, ctypes.POINTER(_I), _I, _P, _P, _I, _P, _I, _P, _I, _P]),
     "uspace_layernorm_f32_bf16": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     "uspace_attention_bf16": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "uspace_embed_tokens": (_I, [_P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -60,6 +66,14 @@ SIGNATURES = {
                                       ctypes.POINTER(_P)]),
     "uspace_uvit_graph_launch": (_I, [_P, _P]),
     "uspace_uvit_graph_destroy": (_I, [_P]),
+    "uspace_groupnorm_map_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "uspace_vae_num_params": (_I, [ctypes.POINTER(VaeConfig)]),
+    "uspace_vae_param_numel": (_L, [ctypes.POINTER(VaeConfig), _I]),
+    "uspace_vae_weight_bytes": (_SZ, [ctypes.POINTER(VaeConfig)]),
+    "uspace_vae_workspace_bytes": (_SZ, [ctypes.POINTER(VaeConfig), _I]),
+    "uspace_vae_pack_weights": (_I, [ctypes.POINTER(VaeConfig), ctypes.POINTER(_P), _I, _P, _SZ, _P]),
+    "uspace_vae_decode": (_I, [ctypes.POINTER(VaeConfig), _P, _P, _SZ, _P, _F, _P, _I, _P]),
+    "uspace_vae_decode_tap": (_I, [ctypes.POINTER(VaeConfig), _P, _P, _SZ, _P, _F, _I, _I, _P, ctypes.POINTER(_I), _P]),
     "uspace_prof_gemm_begin": (_I, [_I, _I, _I, _I]),
     "uspace_prof_gemm_end": (_I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I)]),
 }
@@ -131,6 +145,26 @@ def gemm(A, W, *, A2=None, bias=None, resid=None, gelu=False, out_f32=None, out_
         ptr(out_f32), out_f32.stride(0) if out_f32 is not None else 0,
         ptr(out_bf16), out_bf16.stride(0) if out_bf16 is not None else 0, stream_ptr())
     check(rc, "uspace_gemm_bf16")
+    return out_f32, out_bf16
+
+
+def gemm_slabs(A, W, row_shift, *, bias=None, resid=None, out_f32=None, out_bf16=None, M=None):
+    """acc[m] = sum_t A[m + row_shift[t]] @ W[:, t*K1:(t+1)*K1]^T.  ``A`` points at row 0 of the map (the caller's
+    buffer has guard rows around it); M rows are produced."""
+    require_device(A, "A")
+    K1 = A.shape[1]
+    N = W.shape[0]
+    n = len(row_shift)
+    assert W.shape[1] == n * K1 and A.dtype == torch.bfloat16 and W.dtype == torch.bfloat16
+    M = A.shape[0] if M is None else M
+    flags = (EPI_BIAS if bias is not None else 0) | (EPI_RESIDUAL if resid is not None else 0) | \
+            (EPI_OUT_F32 if out_f32 is not None else 0) | (EPI_OUT_BF16 if out_bf16 is not None else 0)
+    shifts = (ctypes.c_int * n)(*[int(v) for v in row_shift])
+    rc = lib().uspace_gemm_slabs_bf16(
+        ptr(A), A.stride(0), ptr(W), W.stride(0), M, N, K1, n, shifts, flags, ptr(bias), ptr(resid),
+        resid.stride(0) if resid is not None else 0, ptr(out_f32), out_f32.stride(0) if out_f32 is not None else 0,
+        ptr(out_bf16), out_bf16.stride(0) if out_bf16 is not None else 0, stream_ptr())
+    check(rc, "uspace_gemm_slabs_bf16")
     return out_f32, out_bf16
 
 

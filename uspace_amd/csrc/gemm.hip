@@ -31,6 +31,8 @@ struct GemmArgs {
     int M, N, K, K1;
     int lda, lda2, ldw, ld_resid, ld_f32, ld_bf16;
     int tiles_m, tiles_n;
+    int n_slab, k1_log2;  // K is n_slab slabs of K1 = 2^k1_log2 (n_slab > 1); slab s reads A rows shifted by slab_shift[s]
+    int slab_shift[9];    // (3x3 convolution over a zero-bordered NHWC map: 9 taps); 0 for the long-skip's second slab
     int m_main, xrows;   // XTRA: rows [m_main, M) are spread over the workgroups, xrows (<=16) each
 };
 
@@ -129,7 +131,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     const bf16_t* const gA = g.A;
     const bf16_t* const gA2 = g.A2;
     const bf16_t* const gW = g.W;
-    const int K1 = g.K1;
     uint32_t a_off[ISSUES_A];
     uint32_t w_off[ISSUES_W];
 #pragma unroll
@@ -158,10 +159,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     }
     const int wave_lds_off = wave * 8 * ROW_BYTES;  // this wave's 8 rows inside an issue
 
+    const int n_slab = g.n_slab, k1_log2 = g.k1_log2;
+    const long lda_l = g.lda;
+    auto a_base = [&](int k0) -> const char* {
+        // slab s covers K range [s*K1, (s+1)*K1): second operand pointer for the long skip (A2), or the same
+        // map shifted by whole rows for a convolution tap
+        if (n_slab <= 1) return (const char*)(gA + k0);
+        const int sl = k0 >> k1_log2;
+        const int kin = k0 - (sl << k1_log2);
+        const bf16_t* b = (gA2 && sl > 0) ? gA2 : gA;
+        return (const char*)(b + (long)g.slab_shift[sl] * lda_l + kin);
+    };
     auto stage_a = [&](int kt, int buf) {
         const int k0 = kt * BK;
         char* base = smem + buf * STAGE_BYTES;
-        const char* abase = (const char*)(k0 >= K1 ? gA2 + (k0 - K1) : gA + k0);
+        const char* abase = a_base(k0);
 #pragma unroll
         for (int i = 0; i < ISSUES_A; ++i) {
             __builtin_amdgcn_global_load_lds((const US_GLB void*)(abase + a_off[i]),
@@ -448,7 +460,7 @@ int dispatch_tile(const GemmArgs& a, hipStream_t s) {
     // once; otherwise 128x128 tiles (4 waves, ~66 KiB LDS, 2 workgroups/CU).
     const int tn = us_cdiv(a.N, 256);
     const long big_tiles = (long)(a.M / 256) * tn;
-    if (big_tiles < 256) return launch<128, 128, 2, 2, FLAGS>(a, s, 512);
+    if (big_tiles < 256 || a.N <= 128) return launch<128, 128, 2, 2, FLAGS>(a, s, 512);   // N <= 128: no half-empty 256-wide tiles
     // Wave quantisation: when the last round of 256x256 tiles would be mostly empty (e.g. T2I, M = 64*334,
     // N = 1024: 320 tiles = 1.25 rounds), run whole rounds with big tiles and the remaining rows as one
     // round of 128x128 tiles (2 per CU, ~0.55 of a big round) -- rows are independent, so it is two launches.
@@ -471,6 +483,22 @@ int dispatch_tile(const GemmArgs& a, hipStream_t s) {
         }
     }
     return launch<256, 256, 2, 4, FLAGS>(a, s, 256);
+}
+
+int dispatch_flags(const GemmArgs& g, int epi_flags, hipStream_t s) {
+    constexpr int B_ = USPACE_EPI_BIAS, G_ = USPACE_EPI_GELU, R_ = USPACE_EPI_RESIDUAL,
+                  F_ = USPACE_EPI_OUT_F32, H_ = USPACE_EPI_OUT_BF16;
+    switch (epi_flags) {
+        case H_:                return dispatch_tile<H_>(g, s);                 // qkv
+        case B_ | H_:           return dispatch_tile<B_ | H_>(g, s);
+        case B_ | G_ | H_:      return dispatch_tile<B_ | G_ | H_>(g, s);       // fc1 + GELU
+        case B_ | R_ | F_:      return dispatch_tile<B_ | R_ | F_>(g, s);       // proj / fc2 (+= residual)
+        case B_ | R_ | F_ | H_: return dispatch_tile<B_ | R_ | F_ | H_>(g, s);  // ... + bf16 copy (skip stack)
+        case B_ | F_:           return dispatch_tile<B_ | F_>(g, s);            // context_embed
+        case B_ | F_ | H_:      return dispatch_tile<B_ | F_ | H_>(g, s);       // skip_linear
+        case F_:                return dispatch_tile<F_>(g, s);
+        default:                return USPACE_ERR_ARG;
+    }
 }
 
 }  // namespace
@@ -497,20 +525,42 @@ extern "C" int uspace_gemm_bf16(const uint16_t* A, int lda, const uint16_t* A2, 
     g.lda = lda; g.lda2 = lda2; g.ldw = ldw; g.ld_resid = ld_resid; g.ld_f32 = ld_f32; g.ld_bf16 = ld_bf16;
     g.tiles_m = g.tiles_n = 0;
     g.m_main = M; g.xrows = 0;
-    hipStream_t s = (hipStream_t)stream;
-    constexpr int B_ = USPACE_EPI_BIAS, G_ = USPACE_EPI_GELU, R_ = USPACE_EPI_RESIDUAL,
-                  F_ = USPACE_EPI_OUT_F32, H_ = USPACE_EPI_OUT_BF16;
-    switch (epi_flags) {
-        case H_:                return dispatch_tile<H_>(g, s);                 // qkv
-        case B_ | H_:           return dispatch_tile<B_ | H_>(g, s);
-        case B_ | G_ | H_:      return dispatch_tile<B_ | G_ | H_>(g, s);       // fc1 + GELU
-        case B_ | R_ | F_:      return dispatch_tile<B_ | R_ | F_>(g, s);       // proj / fc2 (+= residual)
-        case B_ | R_ | F_ | H_: return dispatch_tile<B_ | R_ | F_ | H_>(g, s);  // ... + bf16 copy (skip stack)
-        case B_ | F_:           return dispatch_tile<B_ | F_>(g, s);            // context_embed
-        case B_ | F_ | H_:      return dispatch_tile<B_ | F_ | H_>(g, s);       // skip_linear
-        case F_:                return dispatch_tile<F_>(g, s);
-        default:                return USPACE_ERR_ARG;
+    g.n_slab = (K1 < K) ? 2 : 1;
+    g.k1_log2 = 0;
+    for (int i = 0; i < 9; ++i) g.slab_shift[i] = 0;
+    if (K1 < K) {
+        if (K != 2 * K1 || (K1 & (K1 - 1))) return USPACE_ERR_ARG;   // two equal power-of-two slabs
+        while ((1 << g.k1_log2) < K1) ++g.k1_log2;
     }
+    return dispatch_flags(g, epi_flags, (hipStream_t)stream);
+}
+
+// acc[m, n] = sum_t A[m + row_shift[t], 0:K1] . W[n, t*K1:(t+1)*K1]   -- e.g. a 3x3 convolution over a
+// zero-bordered NHWC feature map (rows = pixels, 9 taps), or any sum of row-shifted GEMMs.
+extern "C" int uspace_gemm_slabs_bf16(const uint16_t* A, int lda, const uint16_t* W, int ldw, int M, int N, int K1,
+                                      int n_slab, const int* row_shift, int epi_flags, const float* bias,
+                                      const float* resid_in, int ld_resid, float* out_f32, int ld_f32,
+                                      uint16_t* out_bf16, int ld_bf16, uspace_stream_t stream) {
+    if (!A || !W || !row_shift || M <= 0 || N <= 0 || K1 <= 0 || n_slab < 1 || n_slab > 9) return USPACE_ERR_ARG;
+    if (K1 % BK || (K1 & (K1 - 1)) || (N & 3) || (lda & 7) || (ldw & 7)) return USPACE_ERR_ARG;
+    if ((long)M * lda >= (1L << 30) || (long)N * ldw >= (1L << 30)) return USPACE_ERR_ARG;
+    if ((epi_flags & USPACE_EPI_BIAS) && !bias) return USPACE_ERR_ARG;
+    if ((epi_flags & USPACE_EPI_RESIDUAL) && (!resid_in || (ld_resid & 3))) return USPACE_ERR_ARG;
+    if ((epi_flags & USPACE_EPI_OUT_F32) && (!out_f32 || (ld_f32 & 3))) return USPACE_ERR_ARG;
+    if ((epi_flags & USPACE_EPI_OUT_BF16) && (!out_bf16 || (ld_bf16 & 3))) return USPACE_ERR_ARG;
+    if (!(epi_flags & (USPACE_EPI_OUT_F32 | USPACE_EPI_OUT_BF16))) return USPACE_ERR_ARG;
+    GemmArgs g;
+    g.A = A; g.A2 = nullptr; g.W = W; g.bias = bias; g.resid = resid_in;
+    g.out_f32 = out_f32; g.out_bf16 = out_bf16;
+    g.M = M; g.N = N; g.K = K1 * n_slab; g.K1 = K1;
+    g.lda = lda; g.lda2 = lda; g.ldw = ldw; g.ld_resid = ld_resid; g.ld_f32 = ld_f32; g.ld_bf16 = ld_bf16;
+    g.tiles_m = g.tiles_n = 0;
+    g.m_main = M; g.xrows = 0;
+    g.n_slab = n_slab;
+    g.k1_log2 = 0;
+    while ((1 << g.k1_log2) < K1) ++g.k1_log2;
+    for (int i = 0; i < 9; ++i) g.slab_shift[i] = i < n_slab ? row_shift[i] : 0;
+    return dispatch_flags(g, epi_flags, (hipStream_t)stream);
 }
 
 extern "C" int uspace_prof_gemm_begin(int epi_flags, int N, int K, int max_launches) {

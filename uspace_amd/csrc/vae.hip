@@ -1,0 +1,642 @@
+// SD KL-VAE decoder on gfx950: latents [B,4,h,w] -> images [B,3,R,R]
+// (reference: libs/autoencoder.py:303-409 Decoder.forward, :446-450 FrozenAutoencoderKL.decode).
+//
+// Layout: every feature map is "zero-bordered NHWC": rows = pixels of [B, H+2, W+2], C channels per
+// row, with (W+3) guard rows before and after, so a 3x3 convolution is the sum of 9 row-shifted GEMMs
+// on the bf16 MFMA kernel (uspace_gemm_slabs_bf16) and the zero border IS the conv padding.  fp32 maps
+// carry the residual stream; GroupNorm(+SiLU) turns them into the bf16 operand maps (border re-zeroed).
+// Nearest-2x upsampling writes the next resolution's bf16 operand directly.  The single-head mid-block
+// attention (1024 tokens x 512 channels) runs as two GEMMs per image around a row softmax.
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+constexpr size_t ALIGN = 256;
+inline size_t align_up(size_t v) { return (v + ALIGN - 1) / ALIGN * ALIGN; }
+
+// ------------------------------------------------------------------------------------------ kernels
+// z/scale -> post_quant_conv (1x1) -> conv_in (3x3, pad 1): one block per latent pixel.
+__global__ __launch_bounds__(128) void vae_conv_in_kernel(const float* __restrict__ z, float inv_scale,
+                                                          const float* __restrict__ wq, const float* __restrict__ bq,
+                                                          const float* __restrict__ w, const float* __restrict__ bias,
+                                                          float* __restrict__ out, int h, int wd, int C0) {
+    __shared__ float nb[36];   // post-quant values of the 3x3 neighbourhood, (c, dy, dx) order; 0 outside the image
+    const int pix = blockIdx.x;
+    const int b = pix / (h * wd), yx = pix % (h * wd), y = yx / wd, x = yx % wd;
+    if (threadIdx.x < 36) {
+        const int c = threadIdx.x / 9, t = threadIdx.x % 9, dy = t / 3 - 1, dx = t % 3 - 1;
+        const int yy = y + dy, xx = x + dx;
+        float v = 0.f;
+        if (yy >= 0 && yy < h && xx >= 0 && xx < wd) {
+            v = bq[c];
+            for (int ci = 0; ci < 4; ++ci) v += wq[c * 4 + ci] * (z[((size_t)(b * 4 + ci) * h + yy) * wd + xx] * inv_scale);
+        }
+        nb[threadIdx.x] = v;
+    }
+    __syncthreads();
+    float* o = out + ((size_t)(b * (h + 2) + y + 1) * (wd + 2) + x + 1) * C0;
+    for (int d = threadIdx.x; d < C0; d += blockDim.x) {
+        const float* wr = w + (size_t)d * 36;
+        float s = bias[d];
+#pragma unroll
+        for (int e = 0; e < 36; ++e) s += wr[e] * nb[e];
+        o[d] = s;
+    }
+}
+
+// GroupNorm statistics over the interior pixels: block = (image, pixel chunk), thread = channel (coalesced rows).
+// Each block writes its own partial (sum, sum of squares) per group; gn_finish_kernel adds the chunks in a fixed
+// order, so the result does not depend on block scheduling (repeated decodes are bit-identical).
+__global__ __launch_bounds__(512) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                       int H, int W, int C, int chunks) {
+    const int b = blockIdx.x / chunks, ck = blockIdx.x % chunks;
+    const int c = threadIdx.x;
+    const int npix = H * W;
+    const int per = (npix + chunks - 1) / chunks;
+    const int p0 = ck * per, p1 = min(npix, p0 + per);
+    float s = 0.f, ss = 0.f;
+    if (c < C) {
+        for (int p = p0; p < p1; ++p) {
+            const int y = p / W, xx = p % W;
+            const float v = x[((size_t)(b * (H + 2) + y + 1) * (W + 2) + xx + 1) * C + c];
+            s += v;
+            ss += v * v;
+        }
+    }
+    const int cg = C / 32;   // channels per group: 2..16, a power of two -> a group lives inside one wave
+    for (int o = cg >> 1; o > 0; o >>= 1) {
+        s += __shfl_down(s, o, 64);
+        ss += __shfl_down(ss, o, 64);
+    }
+    if (c < C && (c % cg) == 0) {
+        float* o = partial + (((size_t)b * chunks + ck) * 32 + c / cg) * 2;
+        o[0] = s;
+        o[1] = ss;
+    }
+}
+
+// (sum, sumsq) partials -> (mean, rstd) per (image, group)
+__global__ __launch_bounds__(64) void gn_finish_kernel(const float* __restrict__ partial, float* __restrict__ stats,
+                                                       int BG, int chunks, float inv_n, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BG) return;
+    const int b = i >> 5, g = i & 31;
+    float s = 0.f, ss = 0.f;
+    for (int ck = 0; ck < chunks; ++ck) {
+        const float* p = partial + (((size_t)b * chunks + ck) * 32 + g) * 2;
+        s += p[0];
+        ss += p[1];
+    }
+    const float mean = s * inv_n;
+    const float var = fmaxf(ss * inv_n - mean * mean, 0.f);
+    stats[2 * i] = mean;
+    stats[2 * i + 1] = rsqrtf(var + eps);
+}
+
+// y = (x - mean) * rstd * gamma + beta (+ SiLU) -> bf16 operand map with the border rows zeroed.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       bf16_t* __restrict__ y, int B, int H, int W, int C, int silu) {
+    const int C4 = C >> 2;
+    const long total = (long)B * (H + 2) * (W + 2) * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / C4;
+        const int c = (int)(i % C4) * 4;
+        const int xx = row % (W + 2), yy = (row / (W + 2)) % (H + 2), b = (int)(row / ((long)(W + 2) * (H + 2)));
+        uint2 o = make_uint2(0u, 0u);
+        if (xx >= 1 && xx <= W && yy >= 1 && yy <= H) {
+            const int cg = C / 32;               // 2 at C=64: a 4-channel vector then spans two groups
+            const f32x4 v = *(const f32x4*)(x + row * C + c);
+            const f32x4 gm = *(const f32x4*)(gamma + c);
+            const f32x4 bt = *(const f32x4*)(beta + c);
+            f32x4 r;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int g = (c + 2 * h2) / cg;
+                const float mean = stats[((size_t)b * 32 + g) * 2];
+                const float rstd = stats[((size_t)b * 32 + g) * 2 + 1];
+#pragma unroll
+                for (int e = 2 * h2; e < 2 * h2 + 2; ++e) {
+                    float t = (v[e] - mean) * rstd * gm[e] + bt[e];
+                    if (silu) t = t / (1.0f + __expf(-t));
+                    r[e] = t;
+                }
+            }
+            o.x = pack_bf2(r[0], r[1]);
+            o.y = pack_bf2(r[2], r[3]);
+        }
+        *(uint2*)(y + row * C + c) = o;
+    }
+}
+
+// nearest 2x: fp32 map [B,H+2,W+2,C] interior -> bf16 operand map [B,2H+2,2W+2,C] (border zero)
+__global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ x, bf16_t* __restrict__ y,
+                                                       int B, int H, int W, int C) {
+    const int C4 = C >> 2, H2 = 2 * H, W2 = 2 * W;
+    const long total = (long)B * (H2 + 2) * (W2 + 2) * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / C4;
+        const int c = (int)(i % C4) * 4;
+        const int xx = row % (W2 + 2), yy = (row / (W2 + 2)) % (H2 + 2), b = (int)(row / ((long)(W2 + 2) * (H2 + 2)));
+        uint2 o = make_uint2(0u, 0u);
+        if (xx >= 1 && xx <= W2 && yy >= 1 && yy <= H2) {
+            const int sy = (yy - 1) / 2 + 1, sx = (xx - 1) / 2 + 1;
+            const f32x4 v = *(const f32x4*)(x + ((size_t)(b * (H + 2) + sy) * (W + 2) + sx) * C + c);
+            o.x = pack_bf2(v[0], v[1]);
+            o.y = pack_bf2(v[2], v[3]);
+        }
+        *(uint2*)(y + row * C + c) = o;
+    }
+}
+
+// bf16 operand map interior -> compact token rows [B*H*W, C]
+__global__ __launch_bounds__(256) void gather_interior_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                              int B, int H, int W, int C) {
+    const int C8 = C >> 3;
+    const long total = (long)B * H * W * C8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long tokn = i / C8;
+        const int c = (int)(i % C8) * 8;
+        const int xx = tokn % W, yy = (tokn / W) % H, b = (int)(tokn / ((long)W * H));
+        *(uint4*)(y + tokn * C + c) = *(const uint4*)(x + ((size_t)(b * (H + 2) + yy + 1) * (W + 2) + xx + 1) * C + c);
+    }
+}
+
+// fp32 map interior += compact rows
+__global__ __launch_bounds__(256) void scatter_add_kernel(float* __restrict__ x, const float* __restrict__ t,
+                                                          int B, int H, int W, int C) {
+    const int C4 = C >> 2;
+    const long total = (long)B * H * W * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long tokn = i / C4;
+        const int c = (int)(i % C4) * 4;
+        const int xx = tokn % W, yy = (tokn / W) % H, b = (int)(tokn / ((long)W * H));
+        f32x4* d = (f32x4*)(x + ((size_t)(b * (H + 2) + yy + 1) * (W + 2) + xx + 1) * C + c);
+        *d += *(const f32x4*)(t + tokn * C + c);
+    }
+}
+
+// row softmax of S * scale (fp32 [R, N]) -> bf16 P; one wave per row
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, bf16_t* __restrict__ p,
+                                                           long R, int N, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const float* sr = s + row * N;
+    float mx = -INFINITY;
+    for (int j = lane; j < N; j += 64) mx = fmaxf(mx, sr[j]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < N; j += 64) sum += __expf((sr[j] - mx) * scale);
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int j = lane; j < N; j += 64) p[row * N + j] = f2bf(__expf((sr[j] - mx) * scale) * inv);
+}
+
+// [nb][R][C] bf16 -> [nb][C][R]
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int R, int C) {
+    __shared__ bf16_t tile[32][33];
+    const int bz = blockIdx.z;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const bf16_t* xs = x + (size_t)bz * R * C;
+    bf16_t* ys = y + (size_t)bz * R * C;
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < R && c0 + tx < C) tile[j][tx] = xs[(size_t)(r0 + j) * C + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < C && r0 + tx < R) ys[(size_t)(c0 + j) * R + r0 + tx] = tile[tx][j];
+}
+
+// conv_out: bf16 operand map (after norm_out + SiLU) -> Conv2d(C, 3, 3, pad 1) -> NCHW fp32 image.
+// Weights repacked [3][9][C] fp32 in LDS; one thread per output pixel.
+__global__ __launch_bounds__(256) void vae_conv_out_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           int B, int H, int W, int C) {
+    extern __shared__ __attribute__((aligned(16))) float sw[];   // [3][9][C]
+    for (int i = threadIdx.x; i < 27 * C; i += blockDim.x) sw[i] = w[i];
+    __syncthreads();
+    const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= (long)B * H * W) return;
+    const int xx = pix % W, yy = (pix / W) % H, b = (int)(pix / ((long)W * H));
+    float a0 = bias[0], a1 = bias[1], a2 = bias[2];
+    for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3 - 1, dx = t % 3 - 1;
+        const bf16_t* xr = x + ((size_t)(b * (H + 2) + yy + 1 + dy) * (W + 2) + xx + 1 + dx) * C;
+        const float* w0 = sw + (0 * 9 + t) * C;
+        const float* w1 = sw + (1 * 9 + t) * C;
+        const float* w2 = sw + (2 * 9 + t) * C;
+        for (int c = 0; c < C; c += 8) {
+            const uint4 q = *(const uint4*)(xr + c);
+            const uint32_t u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float lo = __uint_as_float(u[e] << 16), hi = __uint_as_float(u[e] & 0xffff0000u);
+                a0 += lo * w0[c + 2 * e] + hi * w0[c + 2 * e + 1];
+                a1 += lo * w1[c + 2 * e] + hi * w1[c + 2 * e + 1];
+                a2 += lo * w2[c + 2 * e] + hi * w2[c + 2 * e + 1];
+            }
+        }
+    }
+    const size_t plane = (size_t)H * W;
+    float* o = out + (size_t)b * 3 * plane + (size_t)yy * W + xx;
+    o[0] = a0;
+    o[plane] = a1;
+    o[2 * plane] = a2;
+}
+
+// weight repacks (fp32 checkpoint layout -> kernel layout)
+__global__ void repack_conv3_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int Co, int Ci) {
+    const long n = (long)Co * Ci * 9;   // src [Co][Ci][3][3] -> dst [Co][9][Ci]
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int ci = i % Ci, t = (i / Ci) % 9;
+        const long co = i / ((long)Ci * 9);
+        dst[i] = f2bf(src[(co * Ci + ci) * 9 + t]);
+    }
+}
+__global__ void repack_conv3_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int Co, int Ci) {
+    const long n = (long)Co * Ci * 9;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int ci = i % Ci, t = (i / Ci) % 9;
+        const long co = i / ((long)Ci * 9);
+        dst[i] = src[(co * Ci + ci) * 9 + t];
+    }
+}
+
+inline int grid_for(long items, int cap = 4096) {
+    long g = (items + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// ------------------------------------------------------------------------------------------ model description
+enum PKind { P_F32 = 0, P_CONV3_BF16 = 1, P_CONV1_BF16 = 2, P_CONV3_F32T = 3 };
+
+struct PDesc {
+    long numel;
+    PKind kind;
+    int co, ci;
+    size_t offset, bytes;
+};
+
+struct ResIdx {
+    int n1w, n1b, c1w, c1b, n2w, n2b, c2w, c2b, sw = -1, sb = -1;
+    int cin, cout;
+};
+
+struct VaeModel {
+    std::vector<PDesc> p;
+    size_t blob_bytes = 0;
+    int conv_in_w, conv_in_b;
+    ResIdx mid1, mid2;
+    int an_w, an_b, q_w, q_b, k_w, k_b, v_w, v_b, po_w, po_b;
+    std::vector<std::vector<ResIdx>> up;   // [level][block]
+    std::vector<int> us_w, us_b;           // upsample conv per level (-1 at level 0)
+    int no_w, no_b, co_w, co_b, pq_w, pq_b;
+    int n_levels, c_top, z_res, res;
+    int add(long numel, PKind k, int co = 0, int ci = 0) {
+        PDesc d{numel, k, co, ci, blob_bytes, 0};
+        d.bytes = (size_t)numel * ((k == P_CONV3_BF16 || k == P_CONV1_BF16) ? 2 : 4);
+        blob_bytes = align_up(blob_bytes + d.bytes);
+        p.push_back(d);
+        return (int)p.size() - 1;
+    }
+    ResIdx add_res(int cin, int cout) {
+        ResIdx r;
+        r.cin = cin; r.cout = cout;
+        r.n1w = add(cin, P_F32); r.n1b = add(cin, P_F32);
+        r.c1w = add((long)cout * cin * 9, P_CONV3_BF16, cout, cin); r.c1b = add(cout, P_F32);
+        r.n2w = add(cout, P_F32); r.n2b = add(cout, P_F32);
+        r.c2w = add((long)cout * cout * 9, P_CONV3_BF16, cout, cout); r.c2b = add(cout, P_F32);
+        if (cin != cout) { r.sw = add((long)cout * cin, P_CONV1_BF16, cout, cin); r.sb = add(cout, P_F32); }
+        return r;
+    }
+};
+
+bool valid_vae(const uspace_vae_config* c) {
+    if (!c || c->ch <= 0 || c->ch % 64 || c->n_levels < 1 || c->n_levels > 4 || c->num_res_blocks < 0) return false;
+    if (c->resolution <= 0 || c->resolution % (1 << (c->n_levels - 1))) return false;
+    for (int i = 0; i < c->n_levels; ++i) {
+        const int ch = c->ch * c->ch_mult[i];
+        if (c->ch_mult[i] <= 0 || (ch & (ch - 1)) || ch > 512) return false;   // power-of-two channel counts <= 512
+    }
+    return true;
+}
+
+// parameter order = the reference's state_dict order (decoder.*, then post_quant_conv.*)
+VaeModel build_vae(const uspace_vae_config& c) {
+    VaeModel m;
+    m.n_levels = c.n_levels;
+    m.res = c.resolution;
+    m.z_res = c.resolution >> (c.n_levels - 1);
+    int block_in = c.ch * c.ch_mult[c.n_levels - 1];
+    m.c_top = block_in;
+    m.conv_in_w = m.add((long)block_in * 4 * 9, P_F32); m.conv_in_b = m.add(block_in, P_F32);
+    m.mid1 = m.add_res(block_in, block_in);
+    m.an_w = m.add(block_in, P_F32); m.an_b = m.add(block_in, P_F32);
+    m.q_w = m.add((long)block_in * block_in, P_CONV1_BF16, block_in, block_in); m.q_b = m.add(block_in, P_F32);
+    m.k_w = m.add((long)block_in * block_in, P_CONV1_BF16, block_in, block_in); m.k_b = m.add(block_in, P_F32);
+    m.v_w = m.add((long)block_in * block_in, P_CONV1_BF16, block_in, block_in); m.v_b = m.add(block_in, P_F32);
+    m.po_w = m.add((long)block_in * block_in, P_CONV1_BF16, block_in, block_in); m.po_b = m.add(block_in, P_F32);
+    m.mid2 = m.add_res(block_in, block_in);
+    // channel flow follows construction order (levels reversed); state_dict lists up.0 .. up.{n-1}
+    std::vector<int> in_at(c.n_levels);
+    {
+        int bi = block_in;
+        for (int lvl = c.n_levels - 1; lvl >= 0; --lvl) { in_at[lvl] = bi; bi = c.ch * c.ch_mult[lvl]; }
+    }
+    m.up.resize(c.n_levels);
+    m.us_w.assign(c.n_levels, -1);
+    m.us_b.assign(c.n_levels, -1);
+    for (int lvl = 0; lvl < c.n_levels; ++lvl) {
+        int bi = in_at[lvl];
+        const int bo = c.ch * c.ch_mult[lvl];
+        for (int j = 0; j < c.num_res_blocks + 1; ++j) { m.up[lvl].push_back(m.add_res(bi, bo)); bi = bo; }
+        if (lvl != 0) { m.us_w[lvl] = m.add((long)bo * bo * 9, P_CONV3_BF16, bo, bo); m.us_b[lvl] = m.add(bo, P_F32); }
+    }
+    const int c_last = c.ch * c.ch_mult[0];
+    m.no_w = m.add(c_last, P_F32); m.no_b = m.add(c_last, P_F32);
+    m.co_w = m.add((long)3 * c_last * 9, P_CONV3_F32T, 3, c_last); m.co_b = m.add(3, P_F32);
+    m.pq_w = m.add(16, P_F32); m.pq_b = m.add(4, P_F32);
+    return m;
+}
+
+struct VaeWs {
+    size_t fa, fb, hb, xb, stats, tok, q, k, v, vt, s, pr, o, po, total;
+    long guard_rows;
+};
+
+VaeWs plan_vae_ws(const uspace_vae_config& c, const VaeModel& m, int B) {
+    VaeWs w;
+    // largest map: at each level the upsample conv keeps that level's channels at twice the resolution
+    size_t max_f = 0, max_h = 0;
+    int res = m.z_res;
+    int chan = m.c_top;
+    for (int lvl = c.n_levels - 1; lvl >= 0; --lvl) {
+        const size_t rows = (size_t)B * (res + 2) * (res + 2) + 2 * (size_t)(res + 3);
+        const int cmax = chan > c.ch * c.ch_mult[lvl] ? chan : c.ch * c.ch_mult[lvl];
+        max_f = std::max(max_f, rows * cmax * 4);
+        max_h = std::max(max_h, rows * cmax * 2);
+        chan = c.ch * c.ch_mult[lvl];
+        if (lvl != 0) {
+            res *= 2;
+            const size_t rows2 = (size_t)B * (res + 2) * (res + 2) + 2 * (size_t)(res + 3);
+            max_h = std::max(max_h, rows2 * chan * 2);
+            max_f = std::max(max_f, rows2 * chan * 4);
+        }
+    }
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
+    w.fa = take(max_f); w.fb = take(max_f); w.hb = take(max_h); w.xb = take(max_h);
+    w.stats = take((size_t)B * 65 * 64 * 4);
+    const size_t T = (size_t)B * m.z_res * m.z_res, Cc = m.c_top, HW = (size_t)m.z_res * m.z_res;
+    w.tok = take(T * Cc * 2); w.q = take(T * Cc * 2); w.k = take(T * Cc * 2); w.v = take(T * Cc * 2);
+    w.vt = take(T * Cc * 2); w.s = take(HW * HW * 4); w.pr = take(HW * HW * 2); w.o = take(T * Cc * 2);
+    w.po = take(T * Cc * 4);
+    w.total = off;
+    return w;
+}
+
+#define US_TRY(expr)                        \
+    do {                                    \
+        int rc__ = (expr);                  \
+        if (rc__ != USPACE_OK) return rc__; \
+    } while (0)
+
+}  // namespace
+
+// GroupNorm(32, C, eps) (+ SiLU) over a zero-bordered NHWC fp32 map -> bf16 operand map (libs/autoencoder.py:31-32,26-28)
+extern "C" int uspace_groupnorm_map_bf16(const float* x, const float* gamma, const float* beta, uint16_t* y,
+                                         float* stats_scratch, int B, int H, int C, int silu, float eps,
+                                         uspace_stream_t stream) {
+    if (!x || !gamma || !beta || !y || !stats_scratch || B <= 0 || H <= 0) return USPACE_ERR_ARG;
+    if (C < 64 || C > 512 || (C & (C - 1))) return USPACE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = std::max(1, std::min(64, (H * H) / 64));
+    float* partial = stats_scratch + (size_t)B * 64;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(B * chunks), dim3(C), 0, s, x, partial, H, H, C, chunks);
+    US_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_finish_kernel, dim3((B * 32 + 63) / 64), dim3(64), 0, s, partial, stats_scratch, B * 32, chunks,
+                       1.0f / ((float)H * (float)H * (float)(C / 32)), eps);
+    US_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for((long)B * (H + 2) * (H + 2) * (C / 4))), dim3(256), 0, s, x,
+                       stats_scratch, gamma, beta, y, B, H, H, C, silu ? 1 : 0);
+    US_CHECK_LAUNCH();
+    return USPACE_OK;
+}
+
+extern "C" int uspace_vae_num_params(const uspace_vae_config* cfg) {
+    if (!valid_vae(cfg)) return USPACE_ERR_ARG;
+    return (int)build_vae(*cfg).p.size();
+}
+
+extern "C" long uspace_vae_param_numel(const uspace_vae_config* cfg, int index) {
+    if (!valid_vae(cfg)) return USPACE_ERR_ARG;
+    const VaeModel m = build_vae(*cfg);
+    if (index < 0 || index >= (int)m.p.size()) return USPACE_ERR_ARG;
+    return m.p[index].numel;
+}
+
+extern "C" size_t uspace_vae_weight_bytes(const uspace_vae_config* cfg) {
+    return valid_vae(cfg) ? build_vae(*cfg).blob_bytes : 0;
+}
+
+extern "C" size_t uspace_vae_workspace_bytes(const uspace_vae_config* cfg, int B) {
+    if (!valid_vae(cfg) || B <= 0) return 0;
+    const VaeModel m = build_vae(*cfg);
+    return plan_vae_ws(*cfg, m, B).total;
+}
+
+extern "C" int uspace_vae_pack_weights(const uspace_vae_config* cfg, const float* const* params, int n_params,
+                                       void* blob, size_t blob_bytes, uspace_stream_t stream) {
+    if (!valid_vae(cfg) || !params || !blob) return USPACE_ERR_ARG;
+    const VaeModel m = build_vae(*cfg);
+    if (n_params != (int)m.p.size()) return USPACE_ERR_ARG;
+    if (blob_bytes < m.blob_bytes) return USPACE_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < n_params; ++i) {
+        const PDesc& d = m.p[i];
+        if (!params[i]) return USPACE_ERR_ARG;
+        char* dst = (char*)blob + d.offset;
+        switch (d.kind) {
+            case P_F32:
+                if (hipMemcpyAsync(dst, params[i], d.bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return USPACE_ERR_LAUNCH;
+                break;
+            case P_CONV1_BF16:
+                US_TRY(uspace_cast_f32_bf16(params[i], (uint16_t*)dst, d.numel, stream));
+                break;
+            case P_CONV3_BF16:
+                hipLaunchKernelGGL(repack_conv3_bf16_kernel, dim3(grid_for(d.numel)), dim3(256), 0, s, params[i], (bf16_t*)dst, d.co, d.ci);
+                US_CHECK_LAUNCH();
+                break;
+            case P_CONV3_F32T:
+                hipLaunchKernelGGL(repack_conv3_f32_kernel, dim3(grid_for(d.numel)), dim3(256), 0, s, params[i], (float*)dst, d.co, d.ci);
+                US_CHECK_LAUNCH();
+                break;
+        }
+    }
+    return USPACE_OK;
+}
+
+static int vae_decode_impl(const uspace_vae_config* cfg, const void* blob, void* workspace, size_t workspace_bytes,
+                           const float* z, float scale_factor, float* out, int B, uspace_stream_t stream,
+                           int stop_after, float* dump, int* dump_hc) {
+    if (!valid_vae(cfg) || !blob || !workspace || !z || !out || B <= 0 || scale_factor == 0.f) return USPACE_ERR_ARG;
+    const uspace_vae_config& c = *cfg;
+    const VaeModel m = build_vae(c);
+    const VaeWs w = plan_vae_ws(c, m, B);
+    if (workspace_bytes < w.total) return USPACE_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const char* wb = (const char*)blob;
+    char* ws = (char*)workspace;
+    auto PF = [&](int i) { return (const float*)(wb + m.p[i].offset); };
+    auto PH = [&](int i) { return (const uint16_t*)(wb + m.p[i].offset); };
+    constexpr int B_ = USPACE_EPI_BIAS, R_ = USPACE_EPI_RESIDUAL, F_ = USPACE_EPI_OUT_F32, H_ = USPACE_EPI_OUT_BF16;
+    float* stats = (float*)(ws + w.stats);
+
+    int stage = 0, cur_c = m.c_top;
+    int H = m.z_res;   // current resolution (square)
+    auto rows_of = [&](int h) { return (long)B * (h + 2) * (h + 2); };
+    auto guard = [&](int h) { return (long)(h + 3); };
+    // map pointers (row 0 sits `guard` rows into the buffer); A = current fp32 map, Bf = scratch fp32 map
+    auto fmap = [&](size_t off, int h, int C) { return (float*)(ws + off) + guard(h) * C; };
+    auto hmap = [&](size_t off, int h, int C) { return (uint16_t*)(ws + off) + guard(h) * C; };
+    size_t cur_off = w.fa, tmp_off = w.fb;
+
+    auto group_norm = [&](const float* x, int h, int C, int gw, int gb, bool silu, uint16_t* y) -> int {
+        return uspace_groupnorm_map_bf16(x, PF(gw), PF(gb), y, stats, B, h, C, silu ? 1 : 0, 1e-6f, stream);
+    };
+    auto conv3 = [&](const uint16_t* a, int h, int Cin, int Cout, int wi, int bi, const float* resid, float* o) -> int {
+        const int P = h + 2;
+        int shifts[9];
+        for (int t = 0; t < 9; ++t) shifts[t] = (t / 3 - 1) * P + (t % 3 - 1);
+        return uspace_gemm_slabs_bf16(a, Cin, PH(wi), 9 * Cin, (int)rows_of(h), Cout, Cin, 9, shifts,
+                                      resid ? (B_ | R_ | F_) : (B_ | F_), PF(bi), resid, Cout, o, Cout, nullptr, 0, stream);
+    };
+    auto resblock = [&](const ResIdx& r, int h) -> int {
+        float* x = fmap(cur_off, h, r.cin);
+        uint16_t* hb = hmap(w.hb, h, r.cin > r.cout ? r.cin : r.cout);
+        US_TRY(group_norm(x, h, r.cin, r.n1w, r.n1b, true, hb));
+        float* t1 = fmap(tmp_off, h, r.cout);
+        US_TRY(conv3(hb, h, r.cin, r.cout, r.c1w, r.c1b, nullptr, t1));
+        US_TRY(group_norm(t1, h, r.cout, r.n2w, r.n2b, true, hb));
+        if (r.cin != r.cout) {
+            // nin_shortcut (1x1) on x, written over t1 (already consumed by norm2), then conv2 accumulates onto it
+            uint16_t* xb = hmap(w.xb, h, r.cin);
+            US_TRY(uspace_cast_f32_bf16(x, xb, rows_of(h) * r.cin, stream));
+            US_TRY(uspace_gemm_bf16(xb, r.cin, nullptr, 0, r.cin, PH(r.sw), r.cin, (int)rows_of(h), r.cout, r.cin, B_ | F_,
+                                    PF(r.sb), nullptr, 0, t1, r.cout, nullptr, 0, stream));
+            US_TRY(conv3(hb, h, r.cout, r.cout, r.c2w, r.c2b, t1, t1));
+            std::swap(cur_off, tmp_off);
+        } else {
+            US_TRY(conv3(hb, h, r.cout, r.cout, r.c2w, r.c2b, x, x));   // x += conv2(...)
+        }
+        return USPACE_OK;
+    };
+
+    // ---- z/scale -> post_quant_conv -> conv_in
+    hipLaunchKernelGGL(vae_conv_in_kernel, dim3(B * H * H), dim3(128), 0, s, z, 1.0f / scale_factor, PF(m.pq_w), PF(m.pq_b),
+                       PF(m.conv_in_w), PF(m.conv_in_b), fmap(cur_off, H, m.c_top), H, H, m.c_top);
+    US_CHECK_LAUNCH();
+#define VAE_STAGE_DONE(CH)                                                                              \
+    do {                                                                                                 \
+        cur_c = (CH);                                                                                    \
+        if (stage++ == stop_after && dump) {                                                             \
+            if (hipMemcpyAsync(dump, fmap(cur_off, H, cur_c), (size_t)rows_of(H) * cur_c * 4,             \
+                               hipMemcpyDeviceToDevice, s) != hipSuccess) return USPACE_ERR_LAUNCH;       \
+            dump_hc[0] = H; dump_hc[1] = cur_c;                                                          \
+            return USPACE_OK;                                                                            \
+        }                                                                                                \
+    } while (0)
+    VAE_STAGE_DONE(m.c_top);
+    // ---- mid: ResnetBlock, AttnBlock, ResnetBlock
+    US_TRY(resblock(m.mid1, H));
+    VAE_STAGE_DONE(m.c_top);
+    {
+        const int Cc = m.c_top, HW = H * H;
+        const long T = (long)B * HW;
+        float* x = fmap(cur_off, H, Cc);
+        uint16_t* hb = hmap(w.hb, H, Cc);
+        US_TRY(group_norm(x, H, Cc, m.an_w, m.an_b, false, hb));
+        uint16_t* tok = (uint16_t*)(ws + w.tok);
+        hipLaunchKernelGGL(gather_interior_kernel, dim3(grid_for(T * (Cc / 8))), dim3(256), 0, s, hb, tok, B, H, H, Cc);
+        US_CHECK_LAUNCH();
+        uint16_t *q = (uint16_t*)(ws + w.q), *k = (uint16_t*)(ws + w.k), *v = (uint16_t*)(ws + w.v);
+        uint16_t *vt = (uint16_t*)(ws + w.vt), *pr = (uint16_t*)(ws + w.pr), *o = (uint16_t*)(ws + w.o);
+        float* sc = (float*)(ws + w.s);
+        float* po = (float*)(ws + w.po);
+        US_TRY(uspace_gemm_bf16(tok, Cc, nullptr, 0, Cc, PH(m.q_w), Cc, (int)T, Cc, Cc, B_ | H_, PF(m.q_b), nullptr, 0, nullptr, 0, q, Cc, stream));
+        US_TRY(uspace_gemm_bf16(tok, Cc, nullptr, 0, Cc, PH(m.k_w), Cc, (int)T, Cc, Cc, B_ | H_, PF(m.k_b), nullptr, 0, nullptr, 0, k, Cc, stream));
+        US_TRY(uspace_gemm_bf16(tok, Cc, nullptr, 0, Cc, PH(m.v_w), Cc, (int)T, Cc, Cc, B_ | H_, PF(m.v_b), nullptr, 0, nullptr, 0, v, Cc, stream));
+        hipLaunchKernelGGL(transpose_kernel, dim3(us_cdiv(Cc, 32), us_cdiv(HW, 32), B), dim3(256), 0, s, v, vt, HW, Cc);
+        US_CHECK_LAUNCH();
+        const float scale = 1.0f / sqrtf((float)Cc);
+        for (int b = 0; b < B; ++b) {
+            // w_ = softmax(q k^T * c^-0.5) over keys; h_ = w_ v   (libs/autoencoder.py:179-191)
+            US_TRY(uspace_gemm_bf16(q + (size_t)b * HW * Cc, Cc, nullptr, 0, Cc, k + (size_t)b * HW * Cc, Cc, HW, HW, Cc, F_,
+                                    nullptr, nullptr, 0, sc, HW, nullptr, 0, stream));
+            hipLaunchKernelGGL(softmax_rows_kernel, dim3(us_cdiv(HW, 4)), dim3(256), 0, s, sc, pr, (long)HW, HW, scale);
+            US_CHECK_LAUNCH();
+            US_TRY(uspace_gemm_bf16(pr, HW, nullptr, 0, HW, vt + (size_t)b * HW * Cc, HW, HW, Cc, HW, H_, nullptr, nullptr, 0,
+                                    nullptr, 0, o + (size_t)b * HW * Cc, Cc, stream));
+        }
+        US_TRY(uspace_gemm_bf16(o, Cc, nullptr, 0, Cc, PH(m.po_w), Cc, (int)T, Cc, Cc, B_ | F_, PF(m.po_b), nullptr, 0, po, Cc, nullptr, 0, stream));
+        hipLaunchKernelGGL(scatter_add_kernel, dim3(grid_for(T * (Cc / 4))), dim3(256), 0, s, x, po, B, H, H, Cc);
+        US_CHECK_LAUNCH();
+    }
+    VAE_STAGE_DONE(m.c_top);
+    US_TRY(resblock(m.mid2, H));
+    VAE_STAGE_DONE(m.c_top);
+    // ---- up path, highest level first
+    for (int lvl = c.n_levels - 1; lvl >= 0; --lvl) {
+        for (const ResIdx& r : m.up[lvl]) {
+            US_TRY(resblock(r, H));
+            VAE_STAGE_DONE(r.cout);
+        }
+        if (lvl != 0) {
+            const int Cc = c.ch * c.ch_mult[lvl];
+            float* x = fmap(cur_off, H, Cc);
+            uint16_t* hb = hmap(w.hb, 2 * H, Cc);
+            hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(rows_of(2 * H) * (Cc / 4))), dim3(256), 0, s, x, hb, B, H, H, Cc);
+            US_CHECK_LAUNCH();
+            H *= 2;
+            float* y = fmap(tmp_off, H, Cc);
+            US_TRY(conv3(hb, H, Cc, Cc, m.us_w[lvl], m.us_b[lvl], nullptr, y));
+            std::swap(cur_off, tmp_off);
+            VAE_STAGE_DONE(Cc);
+        }
+    }
+    // ---- norm_out + SiLU + conv_out -> NCHW image
+    {
+        const int Cc = c.ch * c.ch_mult[0];
+        float* x = fmap(cur_off, H, Cc);
+        uint16_t* hb = hmap(w.hb, H, Cc);
+        US_TRY(group_norm(x, H, Cc, m.no_w, m.no_b, true, hb));
+        const size_t lds = (size_t)27 * Cc * 4;
+        hipLaunchKernelGGL(vae_conv_out_kernel, dim3((unsigned)(((long)B * H * H + 255) / 256)), dim3(256), lds, s, hb,
+                           PF(m.co_w), PF(m.co_b), out, B, H, H, Cc);
+        US_CHECK_LAUNCH();
+    }
+    return USPACE_OK;
+}
+
+extern "C" int uspace_vae_decode(const uspace_vae_config* cfg, const void* blob, void* workspace, size_t workspace_bytes,
+                                 const float* z, float scale_factor, float* out, int B, uspace_stream_t stream) {
+    return vae_decode_impl(cfg, blob, workspace, workspace_bytes, z, scale_factor, out, B, stream, -1, nullptr, nullptr);
+}
+
+// Test aid: run the decode up to (and including) stage `stop_after` -- 0 conv_in, 1 mid.block_1, 2 mid.attn_1,
+// 3 mid.block_2, then one per res block / upsample conv in execution order -- and copy that stage's fp32
+// zero-bordered NHWC map ([B, H+2, H+2, C]) to `dump`; hc_out (host) receives {H, C}.
+extern "C" int uspace_vae_decode_tap(const uspace_vae_config* cfg, const void* blob, void* workspace, size_t workspace_bytes,
+                                     const float* z, float scale_factor, int B, int stop_after, float* dump, int* hc_out,
+                                     uspace_stream_t stream) {
+    if (!dump || !hc_out || stop_after < 0) return USPACE_ERR_ARG;
+    hc_out[0] = hc_out[1] = 0;
+    float dummy_out = 0.f;
+    (void)dummy_out;
+    return vae_decode_impl(cfg, blob, workspace, workspace_bytes, z, scale_factor, dump /*unused unless the tap is past the end*/,
+                           B, stream, stop_after, dump, hc_out);
+}

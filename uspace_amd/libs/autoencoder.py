@@ -132,15 +132,86 @@ class FrozenAutoencoderKL(nn.Module):
             ref = nn.Conv2d(cin, cout, k, padding=k // 2)
             c.weight.copy_(ref.weight)
             c.bias.copy_(ref.bias)
-        for name, p in self.named_parameters():
-            if ".norm" in name or name.endswith("norm.weight") or name.endswith("norm.bias"):
-                if p.dim() == 1 and ("norm" in name.split(".")[-2]):
-                    p.fill_(1.0 if name.endswith("weight") else 0.0)
+        for name, p in self.named_parameters():       # GroupNorm affine defaults
+            if name.split(".")[-2].startswith("norm"):
+                p.fill_(1.0 if name.endswith("weight") else 0.0)
 
     def load_state_dict(self, state_dict, strict=True):
         """Accepts a full autoencoder checkpoint: ``encoder.*`` / ``quant_conv.*`` entries are ignored."""
         sd = {k: v for k, v in state_dict.items() if not (k.startswith("encoder.") or k.startswith("quant_conv."))}
         return super().load_state_dict(sd, strict=strict)
+
+    # ------------------------------------------------------------------ HIP decode
+    def _packed_blob(self, device):
+        ps = list(self.parameters())
+        versions = tuple((p.data_ptr(), p._version) for p in ps)
+        if self._packed is not None and self._packed[0] == device and self._packed[1] == versions:
+            return self._packed[2]
+        L = _hip.lib()
+        mult = (ctypes.c_int * 4)(*(list(self.ch_mult) + [0] * (4 - len(self.ch_mult))))
+        self._cfg = _hip.VaeConfig(self.ch, mult, len(self.ch_mult), self.num_res_blocks, self.resolution)
+        n = L.uspace_vae_num_params(ctypes.byref(self._cfg))
+        if n != len(ps):
+            raise _hip.UspaceHipError(f"VAE parameter count mismatch: module {len(ps)} vs library {n}")
+        srcs = []
+        for i, p in enumerate(ps):
+            _hip.require_device(p, "parameter")
+            if p.numel() != L.uspace_vae_param_numel(ctypes.byref(self._cfg), i):
+                raise _hip.UspaceHipError(f"VAE parameter {i}: unexpected size {tuple(p.shape)}")
+            srcs.append(p.detach().to(torch.float32).contiguous())
+        nbytes = L.uspace_vae_weight_bytes(ctypes.byref(self._cfg))
+        blob = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        arr = (ctypes.c_void_p * n)(*[t.data_ptr() for t in srcs])
+        _hip.check(L.uspace_vae_pack_weights(ctypes.byref(self._cfg), arr, n, _hip.ptr(blob), nbytes, _hip.stream_ptr()),
+                   "uspace_vae_pack_weights")
+        torch.cuda.current_stream().synchronize()
+        self._packed = (device, versions, blob)
+        return blob
+
+    def decode(self, z, chunk=8):
+        """z [B,4,h,h] (scaled latents, as produced by the sampler) -> images [B,3,R,R] fp32.  Decodes ``chunk``
+        images at a time (the reference chunks by 50, dissect_lfm.py:86-98)."""
+        _hip.require_device(z, "z")
+        if z.dim() != 4 or z.shape[1] != self.z_channels or z.shape[2] != self.z_res or z.shape[3] != self.z_res:
+            raise ValueError(f"z must be [B,{self.z_channels},{self.z_res},{self.z_res}], got {tuple(z.shape)}")
+        dev = z.device
+        blob = self._packed_blob(dev)
+        L = _hip.lib()
+        zin = z.detach().to(torch.float32).contiguous()
+        B = zin.shape[0]
+        out = torch.empty(B, self.out_ch, self.resolution, self.resolution, dtype=torch.float32, device=dev)
+        max_chunk = max(1, ((1 << 30) - 1) // ((self.resolution + 2) ** 2 * 512))
+        chunk = max(1, min(chunk, max_chunk, B))
+        key = (chunk, str(dev))
+        if key not in self._ws:
+            nbytes = L.uspace_vae_workspace_bytes(ctypes.byref(self._cfg), chunk)
+            self._ws = {key: torch.empty(nbytes, dtype=torch.uint8, device=dev)}
+        ws = self._ws[key]
+        for lo in range(0, B, chunk):
+            n = min(chunk, B - lo)
+            _hip.check(L.uspace_vae_decode(ctypes.byref(self._cfg), _hip.ptr(blob), _hip.ptr(ws), ws.numel(),
+                                           _hip.ptr(zin[lo:lo + n]), float(self.scale_factor), _hip.ptr(out[lo:lo + n]),
+                                           n, _hip.stream_ptr()), "uspace_vae_decode")
+        return out if z.dtype == torch.float32 else out.to(z.dtype)
+
+    def decode_tap(self, z, stage):
+        """Test aid: the fp32 feature map after ``stage`` (see uspace_vae_decode_tap) as [B, C, H, W]."""
+        dev = z.device
+        blob = self._packed_blob(dev)
+        L = _hip.lib()
+        zin = z.detach().to(torch.float32).contiguous()
+        B = zin.shape[0]
+        nbytes = L.uspace_vae_workspace_bytes(ctypes.byref(self._cfg), B)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        dump = torch.zeros(B * (self.resolution + 2) ** 2 * 512, dtype=torch.float32, device=dev)
+        hc = (ctypes.c_int * 2)()
+        _hip.check(L.uspace_vae_decode_tap(ctypes.byref(self._cfg), _hip.ptr(blob), _hip.ptr(ws), ws.numel(), _hip.ptr(zin),
+                                           float(self.scale_factor), B, int(stage), _hip.ptr(dump), hc, _hip.stream_ptr()),
+                   "uspace_vae_decode_tap")
+        torch.cuda.synchronize()
+        H, C = hc[0], hc[1]
+        m = dump[: B * (H + 2) * (H + 2) * C].view(B, H + 2, H + 2, C)
+        return m[:, 1:-1, 1:-1, :].permute(0, 3, 1, 2).contiguous()
 
     def forward(self, inputs, fn):
         if fn == "decode":
