@@ -204,7 +204,7 @@ typedef struct uspace_vae_config {
 
 /* GroupNorm(32 groups, C, eps) (+ x*sigmoid(x) when silu != 0) over a zero-bordered NHWC fp32 map
  * [B, H+2, H+2, C] -> bf16 operand map of the same geometry with the border rows zeroed
- * (libs/autoencoder.py:26-32).  C a power of two in [64, 512]; stats_scratch: device float[B*65*64].
+ * (libs/autoencoder.py:26-32).  C a power of two in [64, 512]; stats_scratch: device float[B*257*64].
  * Deterministic (no atomics): repeated calls give bit-identical results. */
 USPACE_API int uspace_groupnorm_map_bf16(const float* x, const float* gamma, const float* beta, uint16_t* y,
                                          float* stats_scratch, int B, int H, int C, int silu, float eps,

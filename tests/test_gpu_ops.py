@@ -239,7 +239,7 @@ def test_groupnorm_on_zero_bordered_map(hip, B, C_, H, silu):
     pad[:, 1:-1, 1:-1, :] = torch.from_numpy(x).permute(0, 2, 3, 1)
     xm = pad.contiguous().cuda()
     y = torch.empty(B, H + 2, H + 2, C_, dtype=torch.bfloat16, device="cuda")
-    scratch = torch.empty(B * 65 * 64, device="cuda")
+    scratch = torch.empty(B * 257 * 64, device="cuda")
     gd, bd = to_dev(g), to_dev(bt)
     rc = hip.lib().uspace_groupnorm_map_bf16(hip.ptr(xm), hip.ptr(gd), hip.ptr(bd), hip.ptr(y), hip.ptr(scratch),
                                              B, H, C_, silu, ctypes.c_float(1e-6), hip.stream_ptr())

@@ -61,6 +61,12 @@ def main():
         tot_f += fl * cnt
         print(f"gemm {name:5s} M={M} N={N} K={K}: {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TFLOP/s")
     print(f"  -> all GEMMs of one forward: {tot_t*1e3:.2f} ms, {tot_f/tot_t/1e12:.1f} TFLOP/s aggregate")
+    # ablation: the fc1 shape without the GELU in its epilogue (bias + bf16 store only)
+    W = (torch.randn(4 * D, D, device=dev) * 0.02).to(bf)
+    b = torch.zeros(4 * D, device=dev)
+    o = torch.empty(M, 4 * D, device=dev, dtype=bf)
+    t = timeit(lambda: _hip.gemm(x, W, bias=b, out_bf16=o))
+    print(f"gemm fc1 without GELU (ablation):        {t*1e6:9.1f} us  {2.0*M*4*D*D/t/1e12:7.1f} TFLOP/s")
     H = D // 64
     qkv = torch.randn(M, 3 * D, device=dev).to(bf)
     t = timeit(lambda: _hip.attention(qkv, a.B, a.L, H))

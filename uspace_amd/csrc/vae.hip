@@ -47,88 +47,110 @@ __global__ __launch_bounds__(128) void vae_conv_in_kernel(const float* __restric
     }
 }
 
-// GroupNorm statistics over the interior pixels: block = (image, pixel chunk), thread = channel (coalesced rows).
-// Each block writes its own partial (sum, sum of squares) per group; gn_finish_kernel adds the chunks in a fixed
-// order, so the result does not depend on block scheduling (repeated decodes are bit-identical).
-__global__ __launch_bounds__(512) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ partial,
-                                                       int H, int W, int C, int chunks) {
+// GroupNorm statistics over the interior pixels.  Block = (image, pixel chunk); a thread owns one 4-channel
+// vector (16 B loads, a pixel row of C floats is read by C/4 adjacent lanes) and strides over the chunk's
+// pixels.  Per-thread half-vector sums go through LDS and 32 threads add the 16 contributions of their group
+// in a fixed order; gn_finish_kernel adds the chunks, again in a fixed order, so repeated decodes are
+// bit-identical (no atomics).
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                       int H, int W, int C, int c4_log2, int chunks) {
+    __shared__ float red[256 * 4];
     const int b = blockIdx.x / chunks, ck = blockIdx.x % chunks;
-    const int c = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int C4 = 1 << c4_log2;
+    const int q = tid & (C4 - 1), ps = tid >> c4_log2, PS = 256 >> c4_log2;
     const int npix = H * W;
     const int per = (npix + chunks - 1) / chunks;
     const int p0 = ck * per, p1 = min(npix, p0 + per);
-    float s = 0.f, ss = 0.f;
-    if (c < C) {
-        for (int p = p0; p < p1; ++p) {
-            const int y = p / W, xx = p % W;
-            const float v = x[((size_t)(b * (H + 2) + y + 1) * (W + 2) + xx + 1) * C + c];
-            s += v;
-            ss += v * v;
-        }
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+    const float* xb = x + (size_t)b * (H + 2) * (W + 2) * C + 4 * q;
+#pragma unroll 4
+    for (int p = p0 + ps; p < p1; p += PS) {
+        const int y = p / W, xx = p - y * W;
+        const f32x4 v = *(const f32x4*)(xb + (size_t)((y + 1) * (W + 2) + xx + 1) * C);
+        s0 += v[0] + v[1];
+        q0 += v[0] * v[0] + v[1] * v[1];
+        s1 += v[2] + v[3];
+        q1 += v[2] * v[2] + v[3] * v[3];
     }
-    const int cg = C / 32;   // channels per group: 2..16, a power of two -> a group lives inside one wave
-    for (int o = cg >> 1; o > 0; o >>= 1) {
-        s += __shfl_down(s, o, 64);
-        ss += __shfl_down(ss, o, 64);
-    }
-    if (c < C && (c % cg) == 0) {
-        float* o = partial + (((size_t)b * chunks + ck) * 32 + c / cg) * 2;
+    red[tid * 4 + 0] = s0;
+    red[tid * 4 + 1] = q0;
+    red[tid * 4 + 2] = s1;
+    red[tid * 4 + 3] = q1;
+    __syncthreads();
+    if (tid < 32) {
+        const int hpg = C >> 6;                   // half-vectors (2 channels) per group: 1..8
+        float s = 0.f, ss = 0.f;
+        for (int r = 0; r < PS; ++r)
+            for (int j = 0; j < hpg; ++j) {
+                const int hq = tid * hpg + j;     // half-vector index inside the pixel row
+                const float* e = red + ((r << c4_log2) + (hq >> 1)) * 4 + (hq & 1) * 2;
+                s += e[0];
+                ss += e[1];
+            }
+        float* o = partial + (((size_t)b * chunks + ck) * 32 + tid) * 2;
         o[0] = s;
         o[1] = ss;
     }
 }
 
-// (sum, sumsq) partials -> (mean, rstd) per (image, group)
+// (sum, sumsq) partials -> (mean, rstd) per (image, group): one wave per pair, butterfly reduction
 __global__ __launch_bounds__(64) void gn_finish_kernel(const float* __restrict__ partial, float* __restrict__ stats,
-                                                       int BG, int chunks, float inv_n, float eps) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= BG) return;
+                                                       int chunks, float inv_n, float eps) {
+    const int i = blockIdx.x;
     const int b = i >> 5, g = i & 31;
     float s = 0.f, ss = 0.f;
-    for (int ck = 0; ck < chunks; ++ck) {
+    for (int ck = threadIdx.x; ck < chunks; ck += 64) {
         const float* p = partial + (((size_t)b * chunks + ck) * 32 + g) * 2;
         s += p[0];
         ss += p[1];
     }
-    const float mean = s * inv_n;
-    const float var = fmaxf(ss * inv_n - mean * mean, 0.f);
-    stats[2 * i] = mean;
-    stats[2 * i + 1] = rsqrtf(var + eps);
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    if (threadIdx.x == 0) {
+        const float mean = s * inv_n;
+        const float var = fmaxf(ss * inv_n - mean * mean, 0.f);
+        stats[2 * i] = mean;
+        stats[2 * i + 1] = rsqrtf(var + eps);
+    }
 }
 
 // y = (x - mean) * rstd * gamma + beta (+ SiLU) -> bf16 operand map with the border rows zeroed.
+// Block = 256 threads = 256/C4 padded-map rows per step; 32-bit index arithmetic only.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       bf16_t* __restrict__ y, int B, int H, int W, int C, int silu) {
-    const int C4 = C >> 2;
-    const long total = (long)B * (H + 2) * (W + 2) * C4;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long row = i / C4;
-        const int c = (int)(i % C4) * 4;
-        const int xx = row % (W + 2), yy = (row / (W + 2)) % (H + 2), b = (int)(row / ((long)(W + 2) * (H + 2)));
+                                                       bf16_t* __restrict__ y, int B, int H, int W, int C, int c4_log2,
+                                                       int silu) {
+    const int tid = threadIdx.x;
+    const int C4 = 1 << c4_log2;
+    const int c = (tid & (C4 - 1)) * 4, rsub = tid >> c4_log2, RS = 256 >> c4_log2;
+    const unsigned rows_img = (unsigned)(H + 2) * (unsigned)(W + 2);
+    const unsigned rows = (unsigned)B * rows_img;
+    const int cg = C >> 5;                       // 2 at C=64: a 4-channel vector then spans two groups
+    const f32x4 gm = *(const f32x4*)(gamma + c);
+    const f32x4 bt = *(const f32x4*)(beta + c);
+    const int g0 = c / cg, g1 = (c + 2) / cg;
+    for (unsigned row = blockIdx.x * RS + rsub; row < rows; row += gridDim.x * RS) {
+        const unsigned b = row / rows_img, rr = row - b * rows_img;
+        const unsigned yy = rr / (unsigned)(W + 2), xx = rr - yy * (unsigned)(W + 2);
         uint2 o = make_uint2(0u, 0u);
-        if (xx >= 1 && xx <= W && yy >= 1 && yy <= H) {
-            const int cg = C / 32;               // 2 at C=64: a 4-channel vector then spans two groups
-            const f32x4 v = *(const f32x4*)(x + row * C + c);
-            const f32x4 gm = *(const f32x4*)(gamma + c);
-            const f32x4 bt = *(const f32x4*)(beta + c);
+        if (xx >= 1 && xx <= (unsigned)W && yy >= 1 && yy <= (unsigned)H) {
+            const f32x4 v = *(const f32x4*)(x + (size_t)row * C + c);
+            const float m0 = stats[(b * 32 + g0) * 2], r0 = stats[(b * 32 + g0) * 2 + 1];
+            const float m1 = stats[(b * 32 + g1) * 2], r1 = stats[(b * 32 + g1) * 2 + 1];
             f32x4 r;
+            r[0] = (v[0] - m0) * r0 * gm[0] + bt[0];
+            r[1] = (v[1] - m0) * r0 * gm[1] + bt[1];
+            r[2] = (v[2] - m1) * r1 * gm[2] + bt[2];
+            r[3] = (v[3] - m1) * r1 * gm[3] + bt[3];
+            if (silu) {
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                const int g = (c + 2 * h2) / cg;
-                const float mean = stats[((size_t)b * 32 + g) * 2];
-                const float rstd = stats[((size_t)b * 32 + g) * 2 + 1];
-#pragma unroll
-                for (int e = 2 * h2; e < 2 * h2 + 2; ++e) {
-                    float t = (v[e] - mean) * rstd * gm[e] + bt[e];
-                    if (silu) t = t / (1.0f + __expf(-t));
-                    r[e] = t;
-                }
+                for (int e = 0; e < 4; ++e) r[e] = r[e] / (1.0f + __expf(-r[e]));
             }
             o.x = pack_bf2(r[0], r[1]);
             o.y = pack_bf2(r[2], r[3]);
         }
-        *(uint2*)(y + row * C + c) = o;
+        *(uint2*)(y + (size_t)row * C + c) = o;
     }
 }
 
@@ -211,41 +233,57 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
         if (c0 + j < C && r0 + tx < R) ys[(size_t)(c0 + j) * R + r0 + tx] = tile[tx][j];
 }
 
-// conv_out: bf16 operand map (after norm_out + SiLU) -> Conv2d(C, 3, 3, pad 1) -> NCHW fp32 image.
-// Weights repacked [3][9][C] fp32 in LDS; one thread per output pixel.
+// conv_out (C -> 3, libs/autoencoder.py:379,407): too narrow for an MFMA tile.  LPP = C/8 adjacent lanes share a
+// pixel, each holding its 8 channels' 3x9x8 weights in registers for the whole launch; a tap is one coalesced
+// 16 B load per lane (C*2 contiguous bytes per pixel), the three sums are reduced across the LPP lanes.
+// x: bf16 zero-bordered map; w: fp32 [3][9][C]; out: NCHW fp32.
+template <int LPP>
 __global__ __launch_bounds__(256) void vae_conv_out_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ out,
-                                                           int B, int H, int W, int C) {
-    extern __shared__ __attribute__((aligned(16))) float sw[];   // [3][9][C]
-    for (int i = threadIdx.x; i < 27 * C; i += blockDim.x) sw[i] = w[i];
-    __syncthreads();
-    const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pix >= (long)B * H * W) return;
-    const int xx = pix % W, yy = (pix / W) % H, b = (int)(pix / ((long)W * H));
-    float a0 = bias[0], a1 = bias[1], a2 = bias[2];
-    for (int t = 0; t < 9; ++t) {
-        const int dy = t / 3 - 1, dx = t % 3 - 1;
-        const bf16_t* xr = x + ((size_t)(b * (H + 2) + yy + 1 + dy) * (W + 2) + xx + 1 + dx) * C;
-        const float* w0 = sw + (0 * 9 + t) * C;
-        const float* w1 = sw + (1 * 9 + t) * C;
-        const float* w2 = sw + (2 * 9 + t) * C;
-        for (int c = 0; c < C; c += 8) {
-            const uint4 q = *(const uint4*)(xr + c);
+                                                           int B, int H, int W) {
+    constexpr int C = LPP * 8;
+    const int l = threadIdx.x % LPP;
+    const unsigned slot = (blockIdx.x * 256u + threadIdx.x) / LPP, slots = gridDim.x * 256u / LPP;
+    float wr[3][9][8];
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wr[o][t][e] = w[(o * 9 + t) * C + l * 8 + e];
+    const float b0 = bias[0], b1 = bias[1], b2 = bias[2];
+    const unsigned plane = (unsigned)H * (unsigned)W, npix = (unsigned)B * plane;
+    for (unsigned pix = slot; pix < npix; pix += slots) {
+        const unsigned b = pix / plane, rr = pix - b * plane;
+        const unsigned yy = rr / (unsigned)W, xx = rr - yy * (unsigned)W;
+        const bf16_t* xc = x + ((size_t)(b * (H + 2) + yy + 1) * (W + 2) + xx + 1) * C + l * 8;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            const uint4 q = *(const uint4*)(xc + (dy * (W + 2) + dx) * C);
             const uint32_t u[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float lo = __uint_as_float(u[e] << 16), hi = __uint_as_float(u[e] & 0xffff0000u);
-                a0 += lo * w0[c + 2 * e] + hi * w0[c + 2 * e + 1];
-                a1 += lo * w1[c + 2 * e] + hi * w1[c + 2 * e + 1];
-                a2 += lo * w2[c + 2 * e] + hi * w2[c + 2 * e + 1];
+                a0 += lo * wr[0][t][2 * e] + hi * wr[0][t][2 * e + 1];
+                a1 += lo * wr[1][t][2 * e] + hi * wr[1][t][2 * e + 1];
+                a2 += lo * wr[2][t][2 * e] + hi * wr[2][t][2 * e + 1];
             }
         }
+#pragma unroll
+        for (int o = LPP / 2; o > 0; o >>= 1) {
+            a0 += __shfl_xor(a0, o, 64);
+            a1 += __shfl_xor(a1, o, 64);
+            a2 += __shfl_xor(a2, o, 64);
+        }
+        if (l == 0) {
+            float* op = out + (size_t)b * 3 * plane + rr;
+            op[0] = a0 + b0;
+            op[plane] = a1 + b1;
+            op[2 * plane] = a2 + b2;
+        }
     }
-    const size_t plane = (size_t)H * W;
-    float* o = out + (size_t)b * 3 * plane + (size_t)yy * W + xx;
-    o[0] = a0;
-    o[plane] = a1;
-    o[2 * plane] = a2;
 }
 
 // weight repacks (fp32 checkpoint layout -> kernel layout)
@@ -265,6 +303,8 @@ __global__ void repack_conv3_f32_kernel(const float* __restrict__ src, float* __
         dst[i] = src[(co * Ci + ci) * 9 + t];
     }
 }
+
+constexpr int USPACE_GN_MAX_CHUNKS = 256;
 
 inline int grid_for(long items, int cap = 4096) {
     long g = (items + 255) / 256;
@@ -390,7 +430,7 @@ VaeWs plan_vae_ws(const uspace_vae_config& c, const VaeModel& m, int B) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
     w.fa = take(max_f); w.fb = take(max_f); w.hb = take(max_h); w.xb = take(max_h);
-    w.stats = take((size_t)B * 65 * 64 * 4);
+    w.stats = take((size_t)B * (1 + USPACE_GN_MAX_CHUNKS) * 64 * 4);
     const size_t T = (size_t)B * m.z_res * m.z_res, Cc = m.c_top, HW = (size_t)m.z_res * m.z_res;
     w.tok = take(T * Cc * 2); w.q = take(T * Cc * 2); w.k = take(T * Cc * 2); w.v = take(T * Cc * 2);
     w.vt = take(T * Cc * 2); w.s = take(HW * HW * 4); w.pr = take(HW * HW * 2); w.o = take(T * Cc * 2);
@@ -414,15 +454,19 @@ extern "C" int uspace_groupnorm_map_bf16(const float* x, const float* gamma, con
     if (!x || !gamma || !beta || !y || !stats_scratch || B <= 0 || H <= 0) return USPACE_ERR_ARG;
     if (C < 64 || C > 512 || (C & (C - 1))) return USPACE_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    const int chunks = std::max(1, std::min(64, (H * H) / 64));
+    const int chunks = std::max(1, std::min(USPACE_GN_MAX_CHUNKS, (H * H) / 64));
+    int c4_log2 = 0;
+    while ((4 << c4_log2) < C) ++c4_log2;
     float* partial = stats_scratch + (size_t)B * 64;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(B * chunks), dim3(C), 0, s, x, partial, H, H, C, chunks);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(B * chunks), dim3(256), 0, s, x, partial, H, H, C, c4_log2, chunks);
     US_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_finish_kernel, dim3((B * 32 + 63) / 64), dim3(64), 0, s, partial, stats_scratch, B * 32, chunks,
+    hipLaunchKernelGGL(gn_finish_kernel, dim3(B * 32), dim3(64), 0, s, partial, stats_scratch, chunks,
                        1.0f / ((float)H * (float)H * (float)(C / 32)), eps);
     US_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for((long)B * (H + 2) * (H + 2) * (C / 4))), dim3(256), 0, s, x,
-                       stats_scratch, gamma, beta, y, B, H, H, C, silu ? 1 : 0);
+    const long rows = (long)B * (H + 2) * (H + 2);
+    const int rs = 256 >> c4_log2;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)std::min<long>((rows + rs - 1) / rs, 8192)), dim3(256), 0, s, x,
+                       stats_scratch, gamma, beta, y, B, H, H, C, c4_log2, silu ? 1 : 0);
     US_CHECK_LAUNCH();
     return USPACE_OK;
 }
@@ -614,9 +658,19 @@ static int vae_decode_impl(const uspace_vae_config* cfg, const void* blob, void*
         float* x = fmap(cur_off, H, Cc);
         uint16_t* hb = hmap(w.hb, H, Cc);
         US_TRY(group_norm(x, H, Cc, m.no_w, m.no_b, true, hb));
-        const size_t lds = (size_t)27 * Cc * 4;
-        hipLaunchKernelGGL(vae_conv_out_kernel, dim3((unsigned)(((long)B * H * H + 255) / 256)), dim3(256), lds, s, hb,
-                           PF(m.co_w), PF(m.co_b), out, B, H, H, Cc);
+        const long npix = (long)B * H * H;
+        // 2 waves/SIMD at ~240 VGPRs: 512 workgroups fill the chip once and amortise the per-thread weight load
+        const dim3 grid((unsigned)std::min<long>((npix * (Cc / 8) + 255) / 256, 512));
+#define US_CONV_OUT(LPP)                                                                                              \
+    hipLaunchKernelGGL(vae_conv_out_kernel<LPP>, grid, dim3(256), 0, s, (const bf16_t*)hb, PF(m.co_w), PF(m.co_b), out, B, H, H)
+        switch (Cc) {
+            case 64:  US_CONV_OUT(8); break;
+            case 128: US_CONV_OUT(16); break;
+            case 256: US_CONV_OUT(32); break;
+            case 512: US_CONV_OUT(64); break;
+            default: return USPACE_ERR_ARG;
+        }
+#undef US_CONV_OUT
         US_CHECK_LAUNCH();
     }
     return USPACE_OK;
