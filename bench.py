@@ -207,6 +207,24 @@ def main():
             if world > 1:
                 dist.all_reduce(e, op=dist.ReduceOp.MAX)
             extra = dict(euler50_images_per_sec=B * world / float(e.item()), euler50_nfe=cnf.last_stats.nfe)
+            if world == 1:
+                # latents -> 256^2 images through the VAE decoder; outside the timed region and
+                # outside `value`, reported so the latent->latent figure can be read as an end-to-end one
+                try:
+                    from uspace_amd.libs.autoencoder import get_model
+                    torch.manual_seed(4321)
+                    vae = get_model(None).to(dev)
+                    lat = res[:32].contiguous()
+                    vae.decode(lat, chunk=8)
+                    fence()
+                    t2 = time.perf_counter()
+                    img = vae.decode(lat, chunk=8)
+                    fence()
+                    extra["vae_decode_images_per_sec"] = lat.shape[0] / (time.perf_counter() - t2)
+                    assert img.shape == (lat.shape[0], 3, 256, 256) and bool(torch.isfinite(img).all())
+                    del vae, img
+                except Exception as ex:  # auxiliary figure, never fatal
+                    extra["vae_decode_images_per_sec"] = repr(ex)
 
     if rank == 0:
         L = net.seq_len

@@ -323,3 +323,52 @@ def test_cnf_solver_selection_mirrors_reference():
     net.calls.clear()
     cnf.decode(z, None, dissect_name="bench", edit_loc=None, solver_kwargs=dict(sk, solver="fixed", n_steps=50))
     assert len(net.calls) == 50
+
+
+# ------------------------------------------------------------------------------------------- VAE decoder module
+def test_vae_module_surface_and_seeded_init(golden_dir):
+    """FrozenAutoencoderKL (libs/autoencoder.py:412-450) decode side: reference key order, seeded init bit-equal to
+    the reference's (sha256 from the fixture), full checkpoints load, no CPU decode."""
+    import hashlib
+    from uspace_amd import _hip
+    from uspace_amd.libs.autoencoder import FrozenAutoencoderKL, get_model
+    z = np.load(os.path.join(golden_dir, "vae_decoder_tiny.npz"))
+    meta = json.loads(bytes(z["meta_json"]).decode())
+    torch.manual_seed(meta["weight_seed"])
+    vae = FrozenAutoencoderKL(meta["ddconfig"], 4)
+    sd = vae.state_dict()
+    assert list(sd.keys()) == meta["keys"] and sum(v.numel() for v in sd.values()) == meta["n_params"]
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(v.numpy()).tobytes())
+    assert h.hexdigest() == meta["sha256"]
+    assert not vae.training and not any(p.requires_grad for p in vae.parameters())
+    full = dict(sd)
+    full["encoder.conv_in.weight"] = torch.zeros(3)
+    full["quant_conv.bias"] = torch.zeros(8)
+    vae.load_state_dict(full)                                 # encoder half accepted and ignored
+    with pytest.raises(RuntimeError):
+        vae.load_state_dict({k: v for k, v in sd.items() if k != "decoder.conv_out.bias"})
+    with pytest.raises(_hip.UspaceHipError):
+        vae.decode(torch.zeros(1, 4, 8, 8))                   # host tensor: no CPU path
+    with pytest.raises(NotImplementedError):
+        vae(torch.zeros(1, 4, 8, 8), "encode")
+    with pytest.raises(NotImplementedError):
+        FrozenAutoencoderKL(dict(meta["ddconfig"], attn_resolutions=[8]), 4)
+    big = get_model(None)
+    assert sum(p.numel() for p in big.parameters()) == 49490199 and big.z_res == 32 and big.scale_factor == 0.18215
+
+
+def test_vae_config_queries_without_gpu():
+    from uspace_amd import _hip
+    L = _hip.lib()
+    mult = (ctypes.c_int * 4)(1, 2, 4, 4)
+    cfg = _hip.VaeConfig(128, mult, 4, 2, 256)
+    n = L.uspace_vae_num_params(ctypes.byref(cfg))
+    assert n == 140
+    assert sum(L.uspace_vae_param_numel(ctypes.byref(cfg), i) for i in range(n)) == 49490199
+    assert L.uspace_vae_weight_bytes(ctypes.byref(cfg)) >= 49490199 * 2
+    assert L.uspace_vae_workspace_bytes(ctypes.byref(cfg), 8) > 8 * 258 * 258 * 256 * 4
+    bad = _hip.VaeConfig(100, mult, 4, 2, 256)                # ch not a multiple of 64
+    assert L.uspace_vae_num_params(ctypes.byref(bad)) < 0 and L.uspace_vae_weight_bytes(ctypes.byref(bad)) == 0

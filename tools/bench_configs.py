@@ -20,6 +20,8 @@ CONFIGS = [
     dict(id=3, model="L_t", B=64, solver="euler", n=50, note="configs[2]: U-ViT-L T2I (77 ctx tokens), 50 steps, batch 64"),
     dict(id=4, model="S_t", B=64, solver="euler", n=50, note="configs[3]: U-ViT-S-deep16 T2I, 50 steps, 512/8 = 64 per GPU"),
     dict(id=5, model="L_u", B=32, solver="euler", n=50, hook=True, note="configs[4]: U-ViT-L mid-block u-space edit, 50 steps, 256/8 = 32 per GPU"),
+    dict(id=2, model="L_u", B=64, solver="adaptive", n=0,
+         note="configs[1] with the reference's default solver: adaptive dopri5, rtol = atol = 1e-5 (flow_matching.py:71-73); NFE is measured"),
 ]
 
 
@@ -38,9 +40,13 @@ def run(c, reps=2):
     B = c["B"]
     z = torch.randn(B, 4, 32, 32, generator=g).cuda()
     cond = torch.randn(B, 77, 768, generator=g).cuda() if t2i else None
-    sk = dict(solver="adaptive" if c["solver"] == "dopri5" else "fixed", solver_fix="euler", solver_fix_step=1.0 / c["n"],
-              solver_adaptive="dopri5", solver_adaptive_prec=0.01, n_steps=c["n"])
-    kw = dict(dissect_name="bench", edit_loc=None, solver_kwargs=sk)
+    if c["solver"] == "adaptive":
+        sk = dict(solver="adaptive", solver_fix="euler", solver_fix_step=0.02, solver_adaptive="dopri5", solver_adaptive_prec=1e-5)
+        kw = dict(edit_loc=None, solver_kwargs=sk)          # not a dissection run -> dopri5 at 1e-5, as the reference
+    else:
+        sk = dict(solver="adaptive" if c["solver"] == "dopri5" else "fixed", solver_fix="euler", solver_fix_step=1.0 / c["n"],
+                  solver_adaptive="dopri5", solver_adaptive_prec=0.01, n_steps=c["n"])
+        kw = dict(dissect_name="bench", edit_loc=None, solver_kwargs=sk)
     tmp = None
     if c.get("hook"):
         tmp = tempfile.mkdtemp()
@@ -68,7 +74,11 @@ def run(c, reps=2):
 
 if __name__ == "__main__":
     out = []
+    only = os.environ.get("USPACE_BENCH_ONLY")           # e.g. "4" or "2,5": restrict to these config ids
+    only = {int(v) for v in only.split(",")} if only else None
     for c in CONFIGS:
+        if only and c["id"] not in only:
+            continue
         r = run(c)
         out.append(r)
         print(json.dumps(r))

@@ -217,3 +217,11 @@ class FrozenAutoencoderKL(nn.Module):
         if fn == "decode":
             return self.decode(inputs)
         raise NotImplementedError(f"{fn}: only the decode side is implemented on the MI355X path")
+
+
+def get_model(pretrained_path, scale_factor=0.18215):
+    """The SD KL-f8 autoencoder the reference samples through (libs/autoencoder.py:463-476): 256^2 images,
+    4x32x32 latents, ch=128, multipliers 1-2-4-4, two res blocks per level, no attention in the up path."""
+    sd_vae = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128,
+                  ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    return FrozenAutoencoderKL(sd_vae, 4, pretrained_path, scale_factor)
