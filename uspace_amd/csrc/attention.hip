@@ -1,18 +1,22 @@
 // Non-causal multi-head attention for the short, ragged sequences of U-ViT (L = 257 / 334),
 // head_dim 64, bf16 operands on the gfx950 matrix cores, fp32 softmax.
 //
-// One workgroup (4 waves) owns one (batch, head): the whole K [L,64] and V^T [64,L] of the head
-// live in LDS (66 KB at L=257, 86 KB at L=334 -- SURVEY.md §5), so the score matrix is never
-// materialised and K/V are read from HBM exactly once.  K goes HBM -> LDS by LDS-DMA
-// (global_load_lds, chunk-swizzled on the source side like the GEMM tiles).  Each wave walks
-// 16-query tiles (the next tile's Q fragment is prefetched while the current one computes):
+// One workgroup (4 waves) owns one (batch, head): the whole K [L,64] and V [L,64] of the head live in LDS (70 KB at
+// L=257, 88 KB at L=334 -- SURVEY.md §5), so the score matrix is never materialised and K/V are read from HBM
+// exactly once.  Both go HBM -> LDS by LDS-DMA (global_load_lds; the LDS image is lane-linear, so the
+// bank-spreading chunk swizzles are applied on the source address).  Each wave walks 16-query tiles (the next
+// tile's Q fragment is prefetched while the current one computes):
 //   S^T = K . Q^T   (MFMA A = K rows from LDS, B = Q fragment held in registers)
 //        -> a lane holds, for ONE query (lane&15), 4 consecutive keys of every 16-key tile,
-//           so the row max / row sum are a register sweep plus two cross-lane steps;
+//           so the row max is a register sweep plus two cross-lane steps;
 //   P   = exp2(S*c - max*c), packed to bf16 in place (v_cvt_pk_bf16_f32, no LDS round trip):
 //        the 8 bf16 a lane feeds to the next MFMA are its 4 keys of tile 2u and of tile 2u+1;
-//   O^T = V^T . P^T (MFMA A = V^T rows from LDS with the SAME key->k-slot assignment, B = P)
+//   O^T = V^T . P^T (MFMA A = V^T fragments with the SAME key->k-slot assignment, B = P).  V stays row-major in
+//        LDS; the transposed fragment comes from ds_read_b64_tr_b16 (gfx950's transposing LDS read: within a
+//        16-lane group lane a supplies 4 consecutive bf16 E[a][0..3] and lane i receives E[4j + i/4][i%4],
+//        j = 0..3 -- so when the group points at a [4 keys][16 dims] block, lane i gets dim i of the 4 keys)
 //        -> a lane holds 4 consecutive head-dim outputs of one query: 8-byte bf16 stores.
+//   row sums: one more MFMA per step against an all-ones tile (see below).
 // The optional key_scale[B,L] multiplies P column-wise after normalisation (attention-map edit
 // of the reference, tools/utils_t2i.py:196-224), i.e. it scales P before P.V but not the row sum.
 #include "common.h"
@@ -24,12 +28,17 @@ constexpr int KROW_BYTES = 128;
 
 __device__ __forceinline__ int k_off(int r, int c) { return r * KROW_BYTES + ((c ^ ((r >> 1) & 7)) << 4); }
 
-__host__ __device__ constexpr int vt_stride_bytes(int keys) {
-    // smallest multiple of 16 B that is an ODD multiple of 16 (bank-conflict-free ds_read_b64 across
-    // the 16 head-dim rows a wave touches) and holds `keys` bf16
-    int s = ((keys * 2 + 15) / 16) * 16;
-    if (((s / 16) & 1) == 0) s += 16;
-    return s;
+// V rows are 128 B like K rows, but the transposing read fetches 32-byte pieces of 8 different rows per 32-lane
+// half: 32-B chunk c of row r lives at chunk c ^ ((r >> 1) & 3), which puts those 8 pieces on 8 distinct
+// 32-byte bank groups (row parity selects the 128-B half of the 256-B bank row, the XOR the piece inside it).
+__device__ __forceinline__ int v_off(int r, int c32) { return r * KROW_BYTES + ((c32 ^ ((r >> 1) & 3)) << 5); }
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ uint2 lds_read_tr16(const char* p) {
+    const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+    union { s16x4 v; uint2 u; } c;
+    c.v = r;
+    return c.u;
 }
 
 // NT = number of 16-key tiles the kernel is compiled for (keys beyond L are masked).
@@ -39,16 +48,15 @@ __host__ __device__ constexpr int vt_stride_bytes(int keys) {
 template <int NT, int LC, bool SCALED, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void attention_kernel(const bf16_t* __restrict__ qkv,
                                                            const float* __restrict__ key_scale,
-                                                           bf16_t* __restrict__ out, int L_rt, int H, int vt_stride_rt) {
+                                                           bf16_t* __restrict__ out, int L_rt, int H) {
     const int L = LC > 0 ? LC : L_rt;
-    const int vt_stride = LC > 0 ? vt_stride_bytes(((NT + 1) / 2) * 32) : vt_stride_rt;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NP = (NT + 1) / 2;       // 32-key steps of the P.V product
-    constexpr int KEYS = NP * 32;          // keys covered by V^T rows (zero padded)
+    constexpr int VROWS = NP * 32;         // V rows staged (rows >= L repeat row L-1: finite, their P is 0)
     constexpr int KROWS = NT * 16;
-    char* sK = smem;                                   // [KROWS][64] bf16, chunk-swizzled
-    char* sVt = smem + KROWS * KROW_BYTES;             // [64][vt_stride bytes]: V^T, keys contiguous
-    float* sKs = (float*)(sVt + DH * vt_stride);       // [KROWS] key scale (SCALED only)
+    char* sK = smem;                                   // [KROWS][64] bf16, 16-B chunks swizzled (k_off)
+    char* sV = smem + KROWS * KROW_BYTES;              // [VROWS][64] bf16, 32-B chunks swizzled (v_off)
+    float* sKs = (float*)(sV + VROWS * KROW_BYTES);    // [KROWS] key scale (SCALED only)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -77,28 +85,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void attention_kernel(con
             }
         }
     }
-    // ---- stage V transposed: lane <-> key, so each ds_write_b16 of a wave covers 64 consecutive keys
-#pragma unroll 1
-    for (int key0 = wave * 64; key0 < KEYS; key0 += 64 * NW) {
-        const int key = key0 + lane;
-        if (key < KEYS) {
-            uint4 v[8];
-            const int kk = key < L ? key : L - 1;
+    // ---- stage V the same way (row-major; physical 16-B position cpos holds logical chunk
+    //      (((cpos>>1) ^ ((r>>1)&3)) << 1) | (cpos&1))
+    {
+        const int r8 = lane >> 3, cpos = lane & 7;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) v[c] = *(const uint4*)(gv + (size_t)kk * C3 + c * 8);
-            if (key >= L) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) v[c] = make_uint4(0u, 0u, 0u, 0u);
-            }
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const uint32_t w[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int d = c * 8 + e * 2;
-                    *(bf16_t*)(sVt + (size_t)d * vt_stride + key * 2) = (bf16_t)(w[e] & 0xffffu);
-                    *(bf16_t*)(sVt + (size_t)(d + 1) * vt_stride + key * 2) = (bf16_t)(w[e] >> 16);
-                }
+        for (int blk = 0; blk < (VROWS / 8 + NW - 1) / NW; ++blk) {
+            const int rb = (blk * NW + wave) * 8;
+            if (rb < VROWS) {
+                const int r = rb + r8;
+                const int c = (((cpos >> 1) ^ ((r >> 1) & 3)) << 1) | (cpos & 1);
+                const int rr = r < L ? r : L - 1;
+                __builtin_amdgcn_global_load_lds((const US_GLB void*)(gv + (size_t)rr * C3 + c * 8),
+                                                 (US_LDS void*)(sV + rb * KROW_BYTES), 16, 0, 0);
             }
         }
     }
@@ -131,17 +130,40 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void attention_kernel(con
         int lds_k = 0;
         asm volatile("" : "+v"(lds_k));
 
-        // ---- S^T tiles: s[t][r] = <K[t*16 + 4*fq + r], Q[q0+fr]>
+        // ---- S^T tiles: s[t][r] = <K[t*16 + 4*fq + r], Q[q0+fr]>.  K fragments come from LDS four key tiles at a
+        //      time, one group ahead of the MFMAs that consume them (the compiler's own order issued each read
+        //      right before its MFMA: ~100 cycles of LDS latency per 16-cycle MFMA, with two waves per SIMD to
+        //      hide it).  Inside a group the k-slices are interleaved across tiles so consecutive MFMAs are independent.
         f32x4 s[NT];
+        {
+            constexpr int TQ = 4, NQD = (NT + TQ - 1) / TQ;
+            bf16x8 kb[2][TQ][2];
+            auto load_kq = [&](int qd, bf16x8 (&dst)[TQ][2]) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (t <= t_last) {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const bf16x8 kf = *(const bf16x8*)(sK + lds_k + k_off(t * 16 + fr, ks * 4 + fq));
-                    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
+                for (int j = 0; j < TQ; ++j) {
+                    const int t = qd * TQ + j;
+                    if (t < NT && t <= t_last) {
+                        dst[j][0] = *(const bf16x8*)(sK + lds_k + k_off(t * 16 + fr, fq));
+                        dst[j][1] = *(const bf16x8*)(sK + lds_k + k_off(t * 16 + fr, 4 + fq));
+                    }
                 }
+            };
+#pragma unroll
+            for (int t = 0; t < NT; ++t) s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            load_kq(0, kb[0]);
+#pragma unroll
+            for (int qd = 0; qd < NQD; ++qd) {
+                if (qd + 1 < NQD) load_kq(qd + 1, kb[(qd + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int j = 0; j < TQ; ++j) {
+                        const int t = qd * TQ + j;
+                        if (t < NT && t <= t_last)
+                            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb[qd & 1][j][ks], qf[ks], s[t], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // ---- mask: only the last valid tile can hold keys >= L; tiles after it are all invalid
@@ -157,57 +179,88 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void attention_kernel(con
         // ---- row max
         float mx = s[0][0];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) mx = fmaxf(fmaxf(mx, fmaxf(s[t][0], s[t][1])), fmaxf(s[t][2], s[t][3]));
+        for (int t = 0; t < NT; ++t) {   // two v_max3_f32 per tile (nested form the backend fuses)
+            mx = fmaxf(fmaxf(mx, s[t][0]), s[t][1]);
+            mx = fmaxf(fmaxf(mx, s[t][2]), s[t][3]);
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        // ---- exponentials and row sum: p = 2^(s*c - mx*c)
         const float mc = mx * c_exp;
-        float sum = 0.f;
+        // p = 2^(s*c - mx*c), one 32-key step (two key tiles) at a time
+        auto exp_step = [&](int u) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+            for (int tt = 2 * u; tt < 2 * u + 2 && tt < NT; ++tt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], c_exp, -mc));
-                s[t][r] = p;
-                sum += p;
-            }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
-        if constexpr (SCALED) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const f32x4 k4 = *(const f32x4*)(sKs + t * 16 + fq * 4);
-                s[t] *= k4;
-            }
-        }
-        // ---- O^T = V^T . P^T over 32-key steps; k-slot (fq, e): e<4 -> tile 2u key 4fq+e, e>=4 -> tile 2u+1
-        f32x4 o[4];
+                for (int r = 0; r < 4; ++r) s[tt][r] = __builtin_amdgcn_exp2f(fmaf(s[tt][r], c_exp, -mc));
+        };
+        // ---- O^T = V^T . P^T over 32-key steps; k-slot (fq, e): e<4 -> tile 2u key 4fq+e, e>=4 -> tile 2u+1.
+        //      Software pipeline per step u: V^T fragments of step u+1 are requested, the MFMAs of step u are issued,
+        //      and while the matrix pipe runs them the VALU produces the exponentials and the bf16 pack of step u+1.
+        // The row sum rides on the matrix pipe (which has slack; the loop is VALU-bound by the exponentials): one
+        // more MFMA per 32-key step against an all-ones V^T tile leaves sum_k P[q][k] -- of the SAME bf16-rounded
+        // P that multiplies V -- in every output element, so no per-element adds and no cross-lane reduction.
+        f32x4 o[4], osum = (f32x4){0.f, 0.f, 0.f, 0.f};
+        union { uint32_t w[4]; bf16x8 v; } ones;
+        ones.w[0] = ones.w[1] = ones.w[2] = ones.w[3] = 0x3f803f80u;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        union VF { uint2 h[2]; bf16x8 v; };
+        union PF { uint32_t w[4]; bf16x8 v; };
+        VF vb[2][4];
+        PF pb[2];
+        auto load_v = [&](int u, VF (&dst)[4]) {
+            // group fq of 16 lanes points at V[(2u)*16 + 4fq + 0..3][dt*16 .. +15] (lane a: key row a/4, dims 4(a%4)..+3)
+            // and receives, per lane, dim dt*16+fr of those 4 keys; the second read does tile 2u+1 (16 rows on:
+            // same swizzle key, +2048 B)
+            const int vrow = fq * 4 + (fr >> 2);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const char* pv = sV + v_off(vrow, dt) + ((fr & 3) << 3) + u * (32 * KROW_BYTES);
+                dst[dt].h[0] = lds_read_tr16(pv);
+                dst[dt].h[1] = lds_read_tr16(pv + 16 * KROW_BYTES);
+            }
+        };
+        auto pack_p = [&](int u, PF& pf) {
+            pf.w[0] = pack_bf2(s[2 * u][0], s[2 * u][1]);
+            pf.w[1] = pack_bf2(s[2 * u][2], s[2 * u][3]);
+            if (2 * u + 1 < NT) {
+                pf.w[2] = pack_bf2(s[2 * u + 1][0], s[2 * u + 1][1]);
+                pf.w[3] = pack_bf2(s[2 * u + 1][2], s[2 * u + 1][3]);
+            } else {
+                pf.w[2] = 0u;
+                pf.w[3] = 0u;
+            }
+        };
+        // SCALED (attention-map edit): the column factors multiply P AFTER normalisation (tools/utils_t2i.py:196-224),
+        // so the ones-tile MFMA takes the unscaled pack `pu` and the V^T MFMAs the scaled one; with all factors 1 the
+        // two packs are identical and the result is bit-equal to the unedited kernel.
+        PF pu[SCALED ? 2 : 1];
+        auto make_p = [&](int u) {
+            exp_step(u);
+            if constexpr (SCALED) {
+                pack_p(u, pu[u & 1]);
+#pragma unroll
+                for (int tt = 2 * u; tt < 2 * u + 2 && tt < NT; ++tt) s[tt] *= *(const f32x4*)(sKs + tt * 16 + fq * 4);
+            }
+            pack_p(u, pb[u & 1]);
+        };
+        load_v(0, vb[0]);
+        make_p(0);
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
             if (2 * u <= t_last) {
-                union { uint32_t w[4]; bf16x8 v; } pf;
-                pf.w[0] = pack_bf2(s[2 * u][0], s[2 * u][1]);
-                pf.w[1] = pack_bf2(s[2 * u][2], s[2 * u][3]);
-                if (2 * u + 1 < NT) {
-                    pf.w[2] = pack_bf2(s[2 * u + 1][0], s[2 * u + 1][1]);
-                    pf.w[3] = pack_bf2(s[2 * u + 1][2], s[2 * u + 1][3]);
-                } else {
-                    pf.w[2] = 0u;
-                    pf.w[3] = 0u;
-                }
+                const bool more = (u + 1 < NP) && (2 * (u + 1) <= t_last);
+                if (more) load_v(u + 1, vb[(u + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const char* vrow = sVt + (size_t)(dt * 16 + fr) * vt_stride + (u * 32 + fq * 4) * 2;
-                    union { uint2 h[2]; bf16x8 v; } vf;
-                    vf.h[0] = *(const uint2*)(vrow);
-                    vf.h[1] = *(const uint2*)(vrow + 32);
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, o[dt], 0, 0, 0);
-                }
+                for (int dt = 0; dt < 4; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb[u & 1][dt].v, pb[u & 1].v, o[dt], 0, 0, 0);
+                osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, SCALED ? pu[u & 1].v : pb[u & 1].v, osum, 0, 0, 0);
+                if (more) make_p(u + 1);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        const float inv = 1.0f / osum[0];
         // ---- store: lane holds query q0+fr, head dims dt*16 + 4*fq + {0..3}
         const int q = q0 + fr;
         if (q < L) {
@@ -228,8 +281,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void attention_kernel(con
 template <int NT, int LC, bool SCALED, int NW>
 int launch_attn2(const bf16_t* qkv, const float* ks, bf16_t* out, int B, int L, int H, hipStream_t s) {
     constexpr int NP = (NT + 1) / 2;
-    const int vts = vt_stride_bytes(NP * 32);
-    const size_t lds = (size_t)NT * 16 * KROW_BYTES + (size_t)DH * vts + (SCALED ? NT * 16 * 4 : 0);
+    const size_t lds = (size_t)NT * 16 * KROW_BYTES + (size_t)NP * 32 * KROW_BYTES + (SCALED ? NT * 16 * 4 : 0);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)attention_kernel<NT, LC, SCALED, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -237,7 +289,7 @@ int launch_attn2(const bf16_t* qkv, const float* ks, bf16_t* out, int B, int L, 
             return USPACE_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((attention_kernel<NT, LC, SCALED, NW>), dim3(B * H), dim3(64 * NW), lds, s, qkv, ks, out, L, H, vts);
+    hipLaunchKernelGGL((attention_kernel<NT, LC, SCALED, NW>), dim3(B * H), dim3(64 * NW), lds, s, qkv, ks, out, L, H);
     US_CHECK_LAUNCH();
     return USPACE_OK;
 }
