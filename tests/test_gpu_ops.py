@@ -250,3 +250,59 @@ def test_groupnorm_on_zero_bordered_map(hip, B, C_, H, silu):
     border = yy.clone()
     border[:, 1:-1, 1:-1, :] = 0
     assert float(border.abs().max()) == 0.0                       # zero border = the next conv's padding
+
+
+@pytest.mark.parametrize("B,D,n_extra,time_first", [(3, 128, 0, 1), (2, 512, 1, 0), (2, 1024, 77, 1), (2, 64, 0, 1)])
+def test_embed_tokens_matches_oracle(hip, B, D, n_extra, time_first):
+    """PatchEmbed + timestep_embedding + [label | context] tokens + pos_embed (libs/uvit.py:26-46,171-179,315-327;
+    libs/uvit_t2i.py:320-324), fp32 rows and their bf16 copy; D % 1024 != 0 and the register-weight patch kernel."""
+    rng = np.random.default_rng(D + n_extra)
+    S, p, Cc = 32, 2, 4
+    g = S // p
+    L = 1 + n_extra + g * g
+    img = _rand(rng, B, Cc, S, S)
+    t = rng.uniform(0.05, 0.95, B).astype(np.float32)
+    pw, pb = _rand(rng, D, Cc, p, p, scale=0.2), _rand(rng, D, scale=0.1)
+    pos = _rand(rng, L, D, scale=0.02)
+    extra = _rand(rng, B, max(n_extra, 1), D)
+    patches = C.patch_embed(img, pw, pb)
+    ttok = C.timestep_embedding(t, D)[:, None, :]
+    parts = [ttok, extra[:, :n_extra], patches] if time_first else [extra[:, :n_extra], ttok, patches]
+    ref = np.concatenate(parts, axis=1) + pos[None]
+    d = {k: to_dev(v) for k, v in dict(img=img, t=t, pw=pw, pb=pb, pos=pos, extra=extra).items()}
+    tok = torch.empty(B, L, D, device="cuda")
+    tokb = torch.empty(B, L, D, device="cuda", dtype=torch.bfloat16)
+    rc = hip.lib().uspace_embed_tokens(hip.ptr(d["img"]), hip.ptr(d["t"]), 1, hip.ptr(d["extra"]) if n_extra else None, n_extra,
+                                       time_first, hip.ptr(d["pw"]), hip.ptr(d["pb"]), hip.ptr(d["pos"]), hip.ptr(tok),
+                                       hip.ptr(tokb), B, Cc, S, p, D, hip.stream_ptr())
+    assert rc == 0
+    got = tok.cpu().numpy()
+    assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    assert torch.equal(tokb, tok.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("B,D,extras", [(3, 128, 1), (2, 512, 78), (5, 1024, 1), (2, 64, 2), (1, 1536, 1)])
+def test_output_head_matches_oracle(hip, B, D, extras):
+    """norm + decoder_pred + token slice + unpatchify + final 3x3 conv (libs/uvit.py:56-63,342-347): the LDS-weight
+    kernel (D % 128 == 0, D <= 1024) and the per-token kernel."""
+    import ctypes
+    rng = np.random.default_rng(D + extras)
+    S, p, Cc = 32, 2, 4
+    g = S // p
+    L = extras + g * g
+    x = (_rand(rng, B, L, D, scale=1.5) + 0.3).astype(np.float32)
+    ng, nb = _rand(rng, D) * 0.2 + 1.0, _rand(rng, D, scale=0.1)
+    dw, db = _rand(rng, p * p * Cc, D, scale=0.05), _rand(rng, p * p * Cc, scale=0.1)
+    cw, cb = _rand(rng, Cc, Cc, 3, 3, scale=0.2), _rand(rng, Cc, scale=0.1)
+    h = C.layernorm(x, ng, nb, eps=1e-5)
+    h = C.linear(h, dw, db)[:, extras:, :]
+    ref = C.conv3x3(C.unpatchify(h, Cc), cw, cb)
+    d = {k: to_dev(v) for k, v in dict(x=x, ng=ng, nb=nb, dw=dw, db=db, cw=cw, cb=cb).items()}
+    scratch = torch.empty(B, Cc, S, S, device="cuda")
+    out = torch.empty(B, Cc, S, S, device="cuda")
+    rc = hip.lib().uspace_output_head(hip.ptr(d["x"]), L, extras, hip.ptr(d["ng"]), hip.ptr(d["nb"]), hip.ptr(d["dw"]),
+                                      hip.ptr(d["db"]), hip.ptr(d["cw"]), hip.ptr(d["cb"]), hip.ptr(scratch), hip.ptr(out),
+                                      B, Cc, S, p, D, ctypes.c_float(1e-5), hip.stream_ptr())
+    assert rc == 0
+    got = out.cpu().numpy()
+    assert np.abs(got - ref).max() <= 3e-5 * max(1.0, np.abs(ref).max())

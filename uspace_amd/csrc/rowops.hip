@@ -62,15 +62,17 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ im
                                                     const float* __restrict__ extra, int n_extra, int time_first,
                                                     const float* __restrict__ pw, const float* __restrict__ pb,
                                                     const float* __restrict__ pos, float* __restrict__ tok,
-                                                    bf16_t* __restrict__ tok_bf16, int C, int S, int p, int D) {
+                                                    bf16_t* __restrict__ tok_bf16, int C, int S, int p, int D,
+                                                    int only_special) {
     const int g = S / p;
     const int L = 1 + n_extra + g * g;
-    const int b = blockIdx.x / L;
-    const int l = blockIdx.x % L;
+    const int per = only_special ? 1 + n_extra : L;     // tokens of a sample this launch covers (the leading ones)
+    const int b = blockIdx.x / per;
+    const int l = blockIdx.x % per;
     const int time_pos = time_first ? 0 : n_extra;
     const int extra_pos = time_first ? 1 : 0;
-    float* out = tok + (size_t)blockIdx.x * D;
-    bf16_t* outb = tok_bf16 ? tok_bf16 + (size_t)blockIdx.x * D : nullptr;
+    float* out = tok + ((size_t)b * L + l) * D;
+    bf16_t* outb = tok_bf16 ? tok_bf16 + ((size_t)b * L + l) * D : nullptr;
     const float* posr = pos + (size_t)l * D;
     auto put4 = [&](int d, f32x4 v) {   // D % 4 == 0: 16-byte stores
         v += *(const f32x4*)(posr + d);
@@ -140,6 +142,67 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ im
     }
 }
 
+// Patch tokens, fast path for C*p*p == 16 (every reference config: 4 channels, 2x2 patches).  The per-token kernel
+// above re-reads the [D][16] projection (64 KB at D = 1024) for every one of the B*256 patch tokens: 1 GB through
+// L1/L2 per launch.  Here a thread keeps the 4 x 16 weights of its 4 output channels in registers and a block walks
+// TOK consecutive patch tokens of one sample, whose 16 pixels each sit in LDS: the launch becomes a streaming write
+// (pos_embed read + token rows written, 10 KB per token).
+template <int TOK>
+__global__ __launch_bounds__(256) void embed_patch16_kernel(const float* __restrict__ img, const float* __restrict__ pw,
+                                                            const float* __restrict__ pb, const float* __restrict__ pos,
+                                                            float* __restrict__ tok, bf16_t* __restrict__ tok_bf16,
+                                                            int C, int S, int p, int D, int L, int first_patch) {
+    __shared__ __attribute__((aligned(16))) float px[TOK][16];
+    const int g = S / p;
+    const int npatch = g * g;
+    const int chunks = npatch / TOK;
+    const int b = blockIdx.x / chunks;
+    const int t0 = (blockIdx.x % chunks) * TOK;            // first patch of this block
+    {
+        const int tk = threadIdx.x >> 4, q = threadIdx.x & 15;   // 256 threads = TOK(16) tokens x 16 pixels
+        if (tk < TOK) {
+            const int tp = t0 + tk;
+            const int ph = tp / g, pwid = tp % g;
+            const int c = q / (p * p), ij = q % (p * p);
+            const int i = ij / p, j = ij % p;
+            px[tk][q] = img[(((size_t)b * C + c) * S + ph * p + i) * S + pwid * p + j];
+        }
+    }
+    __syncthreads();
+    for (int d = threadIdx.x * 4; d < D; d += 1024) {
+        f32x4 w[4][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[e][q] = *(const f32x4*)(pw + (size_t)(d + e) * 16 + 4 * q);
+        const f32x4 bias = *(const f32x4*)(pb + d);
+#pragma unroll 4
+        for (int tk = 0; tk < TOK; ++tk) {
+            const size_t row = (size_t)b * L + first_patch + t0 + tk;
+            f32x4 x4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x4[q] = *(const f32x4*)(&px[tk][4 * q]);
+            f32x4 v = bias;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float sacc = v[e];                            // same summation order as the per-token kernel
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    sacc += (w[e][q][0] * x4[q][0] + w[e][q][1] * x4[q][1]) + (w[e][q][2] * x4[q][2] + w[e][q][3] * x4[q][3]);
+                v[e] = sacc;
+            }
+            v += *(const f32x4*)(pos + (size_t)(first_patch + t0 + tk) * D + d);
+            *(f32x4*)(tok + row * D + d) = v;
+            if (tok_bf16) {
+                uint2 qv;
+                qv.x = pack_bf2(v[0], v[1]);
+                qv.y = pack_bf2(v[2], v[3]);
+                *(uint2*)(tok_bf16 + row * D + d) = qv;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Output head, stage 1: LayerNorm + decoder_pred (D -> PD <= 16) on patch tokens + unpatchify.
 // One wave per patch token; 4 tokens per block.
@@ -205,6 +268,137 @@ __global__ __launch_bounds__(256) void head_pred_kernel(const float* __restrict_
             const int c = o % C, p12 = o / C;
             const int p1 = p12 / p, p2 = p12 % p;
             img[(((size_t)b * C + c) * S + ph * p + p1) * S + pwid * p + p2] = r;
+        }
+    }
+}
+
+// Output head, stage 1, fast path (D % 32 == 0, D <= 2048).  The kernel above re-reads the [PD][D] projection for
+// every patch token (64 KB at D = 1024 -> 1 GB through L1/L2 per launch) and spends 18 wave reductions per token.
+// Here LayerNorm is folded through the projection exactly,
+//   out_o = rstd * sum_k (x_k - mean) gamma_k W_ok  +  (b_o + sum_k beta_k W_ok),
+// and the k-sum runs on the matrix cores at fp32-class accuracy: both factors are split into bf16 hi + lo parts
+// (x_c = hi + lo to 2^-17) and three MFMAs per 32-wide k step add W_hi X_hi + W_hi X_lo + W_lo X_hi.  A wave owns 16
+// tokens: lane (fr = token, fq) streams that token's channels 8*fq.. of every k step (128 contiguous bytes per
+// token and step), so mean and centred second moment are per-lane sums plus two cross-lane steps, and the MFMA
+// result leaves lane (fr, fq) holding outputs 4*fq..4*fq+3 of token fr -- no other reduction.  gamma-folded weights sit
+// in LDS as [k/8][16 rows][8] bf16 (hi and lo): a fragment read is 1 KB contiguous per wave.
+template <int UNR>
+__global__ __launch_bounds__(256) void head_pred_mfma_kernel(const float* __restrict__ tok, int L, int extras,
+                                                             const float* __restrict__ ng, const float* __restrict__ nb,
+                                                             const float* __restrict__ dw, const float* __restrict__ db,
+                                                             float* __restrict__ img, int B, int C, int S, int p, int D,
+                                                             float eps) {
+    extern __shared__ __attribute__((aligned(16))) char hsm[];
+    const int PD = p * p * C;                                    // <= 16 (rows >= PD are zero)
+    uint4* wh = (uint4*)hsm;                                     // [D/8][16] x 16 B
+    uint4* wl = wh + 2 * D;
+    float* red = (float*)(wl + 2 * D);                           // [4 waves][16]
+    float* cst = red + 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        float part = 0.f;                                        // thread (row = tid & 15) accumulates beta . W_row over its chunks
+        const int row = tid & 15;
+        for (int c = tid >> 4; c < (D >> 3); c += 16) {
+            union { uint32_t w[4]; uint4 v; } hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float h2[2], l2[2];
+#pragma unroll
+                for (int z = 0; z < 2; ++z) {
+                    const int k = c * 8 + 2 * e + z;
+                    const float wv = row < PD ? dw[(size_t)row * D + k] : 0.f;
+                    part += nb[k] * wv;
+                    const float gw = ng[k] * wv;
+                    h2[z] = bf2f(f2bf(gw));
+                    l2[z] = gw - h2[z];
+                }
+                hi.w[e] = pack_bf2(h2[0], h2[1]);
+                lo.w[e] = pack_bf2(l2[0], l2[1]);
+            }
+            wh[c * 16 + row] = hi.v;
+            wl[c * 16 + row] = lo.v;
+        }
+        // reduce `part` over the 16 threads-per-row groups: lanes with equal (lane & 15) inside a wave, then the waves
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
+        if (lane < 16) red[wave * 16 + lane] = part;
+        __syncthreads();
+        if (tid < 16) cst[tid] = (tid < PD ? db[tid] : 0.f) + ((red[tid] + red[16 + tid]) + (red[32 + tid] + red[48 + tid]));
+        __syncthreads();
+    }
+    const int g = S / p;
+    const int npatch = g * g;
+    const int total = B * npatch;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int idx = (blockIdx.x * 4 + wave) * 16 + fr;
+    const int idc = idx < total ? idx : total - 1;
+    const int b = idc / npatch, tp = idc % npatch;
+    const float* xr = tok + ((size_t)b * L + extras + tp) * D + fq * 8;
+    const int nk = D >> 5;                                        // 32-wide k steps
+    // pass 1: mean
+    float sm = 0.f;
+    for (int k0 = 0; k0 < nk; k0 += UNR) {
+        f32x4 xa[UNR], xc[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int ks = k0 + u < nk ? k0 + u : nk - 1;
+            xa[u] = *(const f32x4*)(xr + ks * 32);
+            xc[u] = *(const f32x4*)(xr + ks * 32 + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            if (k0 + u < nk) sm += ((xa[u][0] + xa[u][1]) + (xa[u][2] + xa[u][3])) + ((xc[u][0] + xc[u][1]) + (xc[u][2] + xc[u][3]));
+    }
+    sm += __shfl_xor(sm, 16, 64);
+    sm += __shfl_xor(sm, 32, 64);
+    const float mean = sm / (float)D;
+    // pass 2: centred second moment and the projection
+    float q = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < nk; k0 += UNR) {
+        f32x4 xa[UNR], xc[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int ks = k0 + u < nk ? k0 + u : nk - 1;
+            xa[u] = *(const f32x4*)(xr + ks * 32);
+            xc[u] = *(const f32x4*)(xr + ks * 32 + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (k0 + u < nk) {
+                const int ks = k0 + u;
+                float v[8] = {xa[u][0] - mean, xa[u][1] - mean, xa[u][2] - mean, xa[u][3] - mean,
+                              xc[u][0] - mean, xc[u][1] - mean, xc[u][2] - mean, xc[u][3] - mean};
+                union { uint32_t w[4]; bf16x8 f; } xh, xl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    q += v[2 * e] * v[2 * e] + v[2 * e + 1] * v[2 * e + 1];
+                    const uint32_t hp = pack_bf2(v[2 * e], v[2 * e + 1]);
+                    xh.w[e] = hp;
+                    xl.w[e] = pack_bf2(v[2 * e] - __uint_as_float(hp << 16), v[2 * e + 1] - __uint_as_float(hp & 0xffff0000u));
+                }
+                union { uint4 v4; bf16x8 f; } fh, fl;
+                fh.v4 = wh[(ks * 4 + fq) * 16 + fr];
+                fl.v4 = wl[(ks * 4 + fq) * 16 + fr];
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh.f, xh.f, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh.f, xl.f, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl.f, xh.f, acc, 0, 0, 0);
+            }
+        }
+    }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = rsqrtf(q / (float)D + eps);
+    if (idx < total) {
+        const int ph = tp / g, pwid = tp % g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = fq * 4 + r;                             // unpatchify "(p1 p2 C)" (libs/uvit.py:60-62)
+            if (o < PD) {
+                const int c = o % C, p12 = o / C;
+                const int p1 = p12 / p, p2 = p12 % p;
+                img[(((size_t)b * C + c) * S + ph * p + p1) * S + pwid * p + p2] = acc[r] * rstd + cst[o];
+            }
         }
     }
 }
@@ -387,8 +581,19 @@ extern "C" int uspace_embed_tokens(const float* img, const float* t, int t_strid
     if (n_extra > 0 && !extra) return USPACE_ERR_ARG;
     const int g = S / p;
     const int L = 1 + n_extra + g * g;
-    hipLaunchKernelGGL(embed_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, img, t, t_stride, extra, n_extra,
-                       time_first, patch_w, patch_b, pos, tok, tok_bf16, C, S, p, D);
+    hipStream_t s = (hipStream_t)stream;
+    constexpr int TOK = 16;
+    if (C * p * p == 16 && (g * g) % TOK == 0) {
+        // time / label / context tokens by the per-token kernel, patch tokens by the register-weight kernel
+        hipLaunchKernelGGL(embed_kernel, dim3(B * (1 + n_extra)), dim3(256), 0, s, img, t, t_stride, extra, n_extra,
+                           time_first, patch_w, patch_b, pos, tok, tok_bf16, C, S, p, D, 1);
+        US_CHECK_LAUNCH();
+        hipLaunchKernelGGL(embed_patch16_kernel<TOK>, dim3(B * (g * g / TOK)), dim3(256), 0, s, img, patch_w, patch_b, pos,
+                           tok, tok_bf16, C, S, p, D, L, 1 + n_extra);
+    } else {
+        hipLaunchKernelGGL(embed_kernel, dim3(B * L), dim3(256), 0, s, img, t, t_stride, extra, n_extra,
+                           time_first, patch_w, patch_b, pos, tok, tok_bf16, C, S, p, D, 0);
+    }
     US_CHECK_LAUNCH();
     return USPACE_OK;
 }
@@ -403,7 +608,18 @@ extern "C" int uspace_output_head(const float* tok, int L, int extras, const flo
     if (extras + g * g != L) return USPACE_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     const dim3 hgrid(us_cdiv(B * g * g, 4)), hblock(256);
-    if (D <= 256) hipLaunchKernelGGL(head_pred_kernel<1>, hgrid, hblock, 0, s, tok, L, extras, norm_g, norm_b, dec_w, dec_b, scratch, B, C, S, p, D, eps);
+    if ((D & 31) == 0 && D <= 2048) {
+        const size_t lds = (size_t)64 * D + (64 + 16) * 4;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)head_pred_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    140 * 1024) != hipSuccess)
+                return USPACE_ERR_LAUNCH;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(head_pred_mfma_kernel<8>, dim3(us_cdiv(B * g * g, 64)), dim3(256), lds, s, tok, L, extras, norm_g,
+                           norm_b, dec_w, dec_b, scratch, B, C, S, p, D, eps);
+    } else if (D <= 256) hipLaunchKernelGGL(head_pred_kernel<1>, hgrid, hblock, 0, s, tok, L, extras, norm_g, norm_b, dec_w, dec_b, scratch, B, C, S, p, D, eps);
     else if (D <= 512) hipLaunchKernelGGL(head_pred_kernel<2>, hgrid, hblock, 0, s, tok, L, extras, norm_g, norm_b, dec_w, dec_b, scratch, B, C, S, p, D, eps);
     else if (D <= 1024) hipLaunchKernelGGL(head_pred_kernel<4>, hgrid, hblock, 0, s, tok, L, extras, norm_g, norm_b, dec_w, dec_b, scratch, B, C, S, p, D, eps);
     else if (D <= 2048) hipLaunchKernelGGL(head_pred_kernel<8>, hgrid, hblock, 0, s, tok, L, extras, norm_g, norm_b, dec_w, dec_b, scratch, B, C, S, p, D, eps);
