@@ -55,37 +55,6 @@ __device__ __forceinline__ float erf_as(float x) {
 }
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752440f)); }
 
-// gelu_erf4: the same function for the fc1 epilogue, where the matrix pipe idles while it runs (24 us of a 170 us
-// launch with the form above: two quarter-rate transcendentals per element dominate).  No transcendental here:
-//   gelu(x) = x/2 + E(x),  E(x) = (x/2) erf(x/sqrt2)  even, smooth, -> |x|/2;
-//   E on |x| <= 5 is a degree-12 polynomial in t = 2 x^2/25 - 1 (Chebyshev fit converted to monomials: all
-//   coefficients <= 1.8 in magnitude, so fp32 Horner is well conditioned); beyond 5, E(x) = E(5) + (|x| - 5)/2.
-// |error| <= 2.9e-6 against the exact erf form over [-12, 12] evaluated in fp32 (1.4e-6 of it is Phi(-5) * 5 at the
-// seam) -- three orders below the bf16 rounding of the stored activation.  Packed fp32 math: 2 elements per
-// v_pk_mul / v_pk_fma.
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
-    const f32x2 sq = x * x;
-    f32x2 s;
-    s[0] = fminf(sq[0], 25.0f);
-    s[1] = fminf(sq[1], 25.0f);
-    const f32x2 t = s * (f32x2){0.08f, 0.08f} + (f32x2){-1.0f, -1.0f};
-    constexpr float c[13] = {1.767047286e+00f,  8.883196712e-01f, -2.346914411e-01f, 1.391499788e-01f, -1.125699654e-01f,
-                             9.676029533e-02f,  -8.555571735e-02f, 8.401805907e-02f, -5.995361134e-02f, 1.565180160e-02f,
-                             -1.156298909e-02f, 2.609798126e-02f,  -1.271393802e-02f};
-    f32x2 p = {c[12], c[12]};
-#pragma unroll
-    for (int k = 11; k >= 0; --k) p = p * t + (f32x2){c[k], c[k]};
-    f32x2 tail;
-    tail[0] = fmaxf(fabsf(x[0]) - 5.0f, 0.0f);
-    tail[1] = fmaxf(fabsf(x[1]) - 5.0f, 0.0f);
-    return (x + tail) * (f32x2){0.5f, 0.5f} + p;
-}
-__device__ __forceinline__ f32x4 gelu_erf4(f32x4 v) {
-    const f32x2 lo = gelu_erf2((f32x2){v[0], v[1]}), hi = gelu_erf2((f32x2){v[2], v[3]});
-    return (f32x4){lo[0], lo[1], hi[0], hi[1]};
-}
-
 #define US_CHECK_LAUNCH()                                   \
     do {                                                    \
         hipError_t e__ = hipGetLastError();                 \

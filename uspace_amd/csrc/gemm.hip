@@ -340,7 +340,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     auto emit = [&](f32x4 v, const f32x4& b, int m, int n) {
         if constexpr (FLAGS & USPACE_EPI_BIAS) v += b;
         if constexpr (FLAGS & USPACE_EPI_GELU) {
-            v = gelu_erf4(v);
+            v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
         }
         if constexpr (FLAGS & USPACE_EPI_OUT_F32) {
             *(f32x4*)(g.out_f32 + (size_t)m * g.ld_f32 + n) = v;
