@@ -240,6 +240,46 @@ USPACE_API int uspace_uvit_graph_create(const uspace_uvit_config* cfg, const voi
 USPACE_API int uspace_uvit_graph_launch(uspace_uvit_graph* g, uspace_stream_t stream);
 USPACE_API int uspace_uvit_graph_destroy(uspace_uvit_graph* g);
 
+/* ------------------------------------------------------------------------------------------------
+ * CLIP text transformer: the encoder behind FrozenCLIPEmbedder (libs/clip.py:40-91), i.e. Hugging Face
+ * CLIPTextModel(input_ids).last_hidden_state -- token + position table lookup, pre-LN blocks with causal attention
+ * (head_dim 64) and a quick-GELU MLP, final LayerNorm.  Tokenisation stays on the host (libs/clip.py:64-72).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct uspace_clip_config {
+    int vocab;    /* 49408 */
+    int dim;      /* 768 = heads * 64 */
+    int heads;    /* 12 */
+    int layers;   /* 12 */
+    int ffn;      /* 3072 */
+    int max_pos;  /* 77 */
+    float eps;    /* 1e-5 */
+} uspace_clip_config;
+
+/* parameter tensors in the HF state_dict order: embeddings.token_embedding.weight, embeddings.position_embedding.weight,
+ * per layer self_attn.{k,v,q,out}_proj.{weight,bias}, layer_norm1.*, mlp.fc1.*, mlp.fc2.*, layer_norm2.*, then
+ * final_layer_norm.{weight,bias} */
+USPACE_API int uspace_clip_num_params(const uspace_clip_config* cfg);
+USPACE_API long uspace_clip_param_numel(const uspace_clip_config* cfg, int index);
+USPACE_API size_t uspace_clip_weight_bytes(const uspace_clip_config* cfg);
+USPACE_API size_t uspace_clip_workspace_bytes(const uspace_clip_config* cfg, int B);
+USPACE_API int uspace_clip_pack_weights(const uspace_clip_config* cfg, const float* const* params, int n_params, void* blob,
+                                        size_t blob_bytes, uspace_stream_t stream);
+/* ids: device int32 [B, L] (L <= max_pos); out: device fp32 [B, L, dim].  stop_after_layer < 0: last_hidden_state;
+ * k >= 0: the hidden state after k layers without the final norm (HF output_hidden_states[k]; test aid). */
+USPACE_API int uspace_clip_text_forward(const uspace_clip_config* cfg, const void* blob, void* workspace, size_t workspace_bytes,
+                                        const int* ids, float* out, int B, int L, int stop_after_layer, uspace_stream_t stream);
+
+/* causal attention over packed qkv (as uspace_attention_bf16, key k visible to query q iff k <= q); L <= 160 */
+USPACE_API int uspace_attention_causal_bf16(const uint16_t* qkv, uint16_t* out, int B, int L, int H, uspace_stream_t stream);
+/* LayerNorm with fp32 output (final norms) */
+USPACE_API int uspace_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int M, int D, float eps,
+                                    uspace_stream_t stream);
+/* out[b,l,:] = tok_table[ids[b,l],:] + pos_table[l,:]  (HF CLIPTextEmbeddings) */
+USPACE_API int uspace_table_embed(const int* ids, const float* tok_table, const float* pos_table, float* out, int B, int L, int D,
+                                  int vocab, uspace_stream_t stream);
+/* x <- x * sigmoid(1.702 x) in place, bf16 (HF QuickGELUActivation); n % 4 == 0 */
+USPACE_API int uspace_quick_gelu_bf16(uint16_t* x, long n, uspace_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * Measurement aid (bench.py): record HIP events, on the launching stream, around every
  * uspace_gemm_bf16 launch whose (epi_flags, N, K) match, up to max_launches; _end() waits for

@@ -19,6 +19,7 @@ What is pinned:
   p2p_t2i                           tools/utils_t2i.py:265 attention-map hook
   attr_directions                   tools/utils_attr.py:124 mean(pos) - mean(neg) attribute directions
   vae_decoder_tiny                  libs/autoencoder.py:303-409,446-450 SD-VAE decoder, tiny config + taps
+  clip_text_tiny                    libs/clip.py:40-91 CLIP text transformer (HF CLIPTextModel), tiny config + hidden states
   big_{S,L}_{u,t}                   seed-regenerated weights (sha256 pinned) -> out, B=2
   euler20_S_u                       BASELINE config 1: 20 fixed Euler steps, B=4, driven by
                                     a plain loop written here around the reference nnet
@@ -431,10 +432,46 @@ def make_vae_decoder():
     save("vae_decoder_tiny.npz", **out)
 
 
+def make_clip_text():
+    """libs/clip.py:40-91 FrozenCLIPEmbedder.forward = HF ``CLIPTextModel(input_ids=tokens).last_hidden_state``.
+    The pretrained weights and the tokenizer files are not in the image, so the fixture is the same HF module
+    (transformers, version recorded below) at a tiny configuration with its own random init: state_dict + token
+    ids -> last_hidden_state and the hidden state after every layer."""
+    import transformers
+    from transformers import CLIPTextConfig, CLIPTextModel
+    cfg = CLIPTextConfig(vocab_size=1000, hidden_size=128, intermediate_size=512, num_hidden_layers=2,
+                         num_attention_heads=2, max_position_embeddings=77, hidden_act="quick_gelu")
+    torch.manual_seed(WEIGHT_SEED + 9)
+    m = CLIPTextModel(cfg).eval()
+    for prm in m.parameters():                       # HF init leaves LayerNorm at (1, 0) and biases at 0: perturb them
+        if prm.dim() == 1:
+            prm.data.add_(0.05 * torch.randn_like(prm))
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, 1000, (3, 77), generator=g)
+    ids[:, 0] = 998                                  # bos-like / eos-like ids: plain table rows here
+    ids[1, 40:] = 999
+    with torch.no_grad():
+        out = m(input_ids=ids, output_hidden_states=True)
+    arrays = {"sd/" + k: v.detach().numpy() for k, v in m.state_dict().items()}
+    for i, h in enumerate(out.hidden_states):
+        arrays[f"hidden/{i}"] = h.numpy()
+    meta = dict(transformers=transformers.__version__, hidden_size=128, intermediate_size=512, num_hidden_layers=2,
+                num_attention_heads=2, max_position_embeddings=77, vocab_size=1000, hidden_act="quick_gelu",
+                layer_norm_eps=cfg.layer_norm_eps, keys=list(m.state_dict().keys()))
+    arrays.update(ids=ids.numpy().astype(np.int64), out=out.last_hidden_state.numpy(),
+                  meta_json=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
+    save("clip_text_tiny.npz", **arrays)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-large", action="store_true")
+    ap.add_argument("--only-clip", action="store_true", help="regenerate only clip_text_tiny.npz (no reference import needed)")
     args = ap.parse_args()
+    if args.only_clip:
+        torch.set_grad_enabled(False)
+        make_clip_text()
+        return
     uvit, uvit_t2i = _refshim.load_reference()
     torch.set_grad_enabled(False)
     m, x = make_tiny_u(uvit)
@@ -444,6 +481,7 @@ def main():
     make_p2p_t2i(mt, xt, ctx)
     make_attr_directions()
     make_vae_decoder()
+    make_clip_text()
     if not args.skip_large:
         timing = dict(threads=torch.get_num_threads(), nproc=os.cpu_count(),
                       cpu=[l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0],

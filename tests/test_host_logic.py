@@ -372,3 +372,45 @@ def test_vae_config_queries_without_gpu():
     assert L.uspace_vae_workspace_bytes(ctypes.byref(cfg), 8) > 8 * 258 * 258 * 256 * 4
     bad = _hip.VaeConfig(100, mult, 4, 2, 256)                # ch not a multiple of 64
     assert L.uspace_vae_num_params(ctypes.byref(bad)) < 0 and L.uspace_vae_weight_bytes(ctypes.byref(bad)) == 0
+
+
+# ------------------------------------------------------------------------------------------- CLIP text encoder module
+def test_clip_module_surface(golden_dir):
+    from uspace_amd import _hip
+    from uspace_amd.libs.clip import CLIPTextTransformer, CLIP_L_TEXT, get_word_inds
+    z = np.load(os.path.join(golden_dir, "clip_text_tiny.npz"))
+    meta = json.loads(bytes(z["meta_json"]).decode())
+    m = CLIPTextTransformer(vocab_size=1000, hidden_size=128, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2)
+    assert list(m.state_dict().keys()) == meta["keys"]                     # HF CLIPTextModel's own key order
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    m.load_state_dict(sd)
+    pref = {"text_model." + k: v for k, v in sd.items()}
+    pref["text_model.embeddings.position_ids"] = torch.arange(77)[None]    # older checkpoints carry this buffer
+    pref["logit_scale"] = torch.zeros(())
+    m.load_state_dict(pref)
+    with pytest.raises(_hip.UspaceHipError):
+        m(torch.zeros(1, 77, dtype=torch.long))                            # host tensor: no CPU path
+    with pytest.raises(NotImplementedError):
+        CLIPTextTransformer(hidden_act="gelu")
+    L = _hip.lib()
+    cfg = _hip.ClipConfig(49408, 768, 12, 12, 3072, 77, 1e-5)
+    n = L.uspace_clip_num_params(ctypes.byref(cfg))
+    assert n == 2 + 16 * 12 + 2
+    assert sum(L.uspace_clip_param_numel(ctypes.byref(cfg), i) for i in range(n)) == 123060480   # CLIP-L text model
+    assert L.uspace_clip_weight_bytes(ctypes.byref(cfg)) > 49408 * 768 * 4
+    assert L.uspace_clip_workspace_bytes(ctypes.byref(cfg), 8) > 8 * 77 * 768 * 4
+    bad = _hip.ClipConfig(49408, 768, 8, 12, 3072, 77, 1e-5)              # head_dim != 64
+    assert L.uspace_clip_num_params(ctypes.byref(bad)) < 0 and L.uspace_clip_weight_bytes(ctypes.byref(bad)) == 0
+
+    class Tok:                                                              # word pieces: "running" -> "run" "##ning"
+        table = {"a": [5], "dog": [6], "running": [7, 8], "fast": [9]}
+        names = {5: "a", 6: "dog", 7: "run", 8: "##ning", 9: "fast"}
+
+        def encode(self, text):
+            return [0] + [i for w in text.split(" ") for i in self.table[w]] + [1]
+
+        def decode(self, ids):
+            return self.names.get(ids[0], "")
+    assert get_word_inds("a dog running fast", "running", Tok()).tolist() == [3, 4]
+    assert get_word_inds("a dog running fast", 3, Tok()).tolist() == [5]
+    assert get_word_inds("a dog running fast", "cat", Tok()).tolist() == []

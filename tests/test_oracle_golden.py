@@ -152,3 +152,18 @@ def test_vae_decoder_oracle_matches_reference(golden_dir):
     for k in [f for f in z.files if f.startswith("tap/")]:
         np.testing.assert_allclose(taps[k[4:]], z[k], rtol=2e-4, atol=2e-5, err_msg=k)
     np.testing.assert_allclose(img, z["img"], rtol=2e-4, atol=2e-5)
+
+
+def test_clip_text_oracle_matches_hf_module(golden_dir):
+    """libs/clip.py:85-88: CLIPTextModel(input_ids).last_hidden_state (HF transformers, tiny random-init config)."""
+    import json
+    from oracle import clip_oracle as K
+    z = np.load(os.path.join(golden_dir, "clip_text_tiny.npz"))
+    meta = json.loads(bytes(z["meta_json"]).decode())
+    sd = {k[3:]: z[k] for k in z.files if k.startswith("sd/")}
+    hidden = []
+    out = K.text_forward(sd, z["ids"], meta["num_attention_heads"], eps=meta["layer_norm_eps"], hidden=hidden)
+    assert len(hidden) == meta["num_hidden_layers"] + 1
+    for i, h in enumerate(hidden):
+        np.testing.assert_allclose(h, z[f"hidden/{i}"], rtol=2e-4, atol=2e-5, err_msg=f"hidden {i}")
+    np.testing.assert_allclose(out, z["out"], rtol=2e-4, atol=2e-5)

@@ -39,6 +39,11 @@ class VaeConfig(ctypes.Structure):
                 ("num_res_blocks", ctypes.c_int), ("resolution", ctypes.c_int)]
 
 
+class ClipConfig(ctypes.Structure):
+    _fields_ = [("vocab", ctypes.c_int), ("dim", ctypes.c_int), ("heads", ctypes.c_int), ("layers", ctypes.c_int),
+                ("ffn", ctypes.c_int), ("max_pos", ctypes.c_int), ("eps", ctypes.c_float)]
+
+
 _P, _I, _L, _F, _SZ = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
 
 # name -> (restype, argtypes); must list every symbol include/uspace_hip.h declares
@@ -74,6 +79,16 @@ SIGNATURES = {
     "uspace_vae_pack_weights": (_I, [ctypes.POINTER(VaeConfig), ctypes.POINTER(_P), _I, _P, _SZ, _P]),
     "uspace_vae_decode": (_I, [ctypes.POINTER(VaeConfig), _P, _P, _SZ, _P, _F, _P, _I, _P]),
     "uspace_vae_decode_tap": (_I, [ctypes.POINTER(VaeConfig), _P, _P, _SZ, _P, _F, _I, _I, _P, ctypes.POINTER(_I), _P]),
+    "uspace_clip_num_params": (_I, [ctypes.POINTER(ClipConfig)]),
+    "uspace_clip_param_numel": (_L, [ctypes.POINTER(ClipConfig), _I]),
+    "uspace_clip_weight_bytes": (_SZ, [ctypes.POINTER(ClipConfig)]),
+    "uspace_clip_workspace_bytes": (_SZ, [ctypes.POINTER(ClipConfig), _I]),
+    "uspace_clip_pack_weights": (_I, [ctypes.POINTER(ClipConfig), _P, _I, _P, _SZ, _P]),
+    "uspace_clip_text_forward": (_I, [ctypes.POINTER(ClipConfig), _P, _P, _SZ, _P, _P, _I, _I, _I, _P]),
+    "uspace_attention_causal_bf16": (_I, [_P, _P, _I, _I, _I, _P]),
+    "uspace_layernorm_f32": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
+    "uspace_table_embed": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "uspace_quick_gelu_bf16": (_I, [_P, _L, _P]),
     "uspace_prof_gemm_begin": (_I, [_I, _I, _I, _I]),
     "uspace_prof_gemm_end": (_I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I)]),
 }

@@ -45,7 +45,8 @@ __device__ __forceinline__ uint2 lds_read_tr16(const char* p) {
 // LC > 0: the sequence length is a compile-time constant (the production lengths 257 and 334), so
 // the tail-tile masks, the tile-skip tests and the V^T stride fold away; LC == 0: generic length.
 // NW = waves per workgroup: 4 when two workgroups fit a CU's LDS (L <= 272), 8 when only one does.
-template <int NT, int LC, bool SCALED, int NW>
+// CAUSAL: key k is visible to query q iff k <= q (CLIP text transformer); the key_scale edit does not apply there.
+template <int NT, int LC, bool SCALED, int NW, bool CAUSAL = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void attention_kernel(const bf16_t* __restrict__ qkv,
                                                            const float* __restrict__ key_scale,
                                                            bf16_t* __restrict__ out, int L_rt, int H) {
@@ -176,6 +177,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void attention_kernel(con
                 s[t] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
             }
         }
+        if constexpr (CAUSAL) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[t][r] = (t * 16 + fq * 4 + r) <= (q0 + fr) ? s[t][r] : -INFINITY;
+        }
         // ---- row max
         float mx = s[0][0];
 #pragma unroll
@@ -301,7 +308,25 @@ int launch_attn(const bf16_t* qkv, const float* ks, bf16_t* out, int B, int L, i
               : launch_attn2<NT, LC, false, NW>(qkv, ks, out, B, L, H, s);
 }
 
+template <int NT>
+int launch_attn_causal(const bf16_t* qkv, bf16_t* out, int B, int L, int H, hipStream_t s) {
+    constexpr int NP = (NT + 1) / 2;
+    const size_t lds = (size_t)NT * 16 * KROW_BYTES + (size_t)NP * 32 * KROW_BYTES;
+    hipLaunchKernelGGL((attention_kernel<NT, 0, false, 4, true>), dim3(B * H), dim3(256), lds, s, qkv, nullptr, out, L, H);
+    US_CHECK_LAUNCH();
+    return USPACE_OK;
+}
+
 }  // namespace
+
+extern "C" int uspace_attention_causal_bf16(const uint16_t* qkv, uint16_t* out, int B, int L, int H, uspace_stream_t stream) {
+    if (!qkv || !out || B <= 0 || L <= 0 || H <= 0) return USPACE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int nt = (L + 15) / 16;
+    if (nt <= 6) return launch_attn_causal<6>(qkv, out, B, L, H, s);     // CLIP: 77 tokens = 5 key tiles
+    if (nt <= 10) return launch_attn_causal<10>(qkv, out, B, L, H, s);
+    return USPACE_ERR_ARG;
+}
 
 extern "C" int uspace_attention_bf16(const uint16_t* qkv, const float* key_scale, uint16_t* out, int B, int L, int H,
                                      uspace_stream_t stream) {

@@ -61,4 +61,10 @@ __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + e
         if (e__ != hipSuccess) return USPACE_ERR_LAUNCH;    \
     } while (0)
 
+#define US_TRY(expr)                        \
+    do {                                    \
+        int rc__ = (expr);                  \
+        if (rc__ != USPACE_OK) return rc__; \
+    } while (0)
+
 static inline int us_cdiv(int a, int b) { return (a + b - 1) / b; }

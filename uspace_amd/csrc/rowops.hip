@@ -9,7 +9,7 @@ namespace {
 // LayerNorm: one wave per row, row kept in registers (fp32 in, bf16 out). D % 4 == 0, D <= 4096.
 // Algorithmic HBM bytes per row: 4*D read + 2*D written.
 // ------------------------------------------------------------------------------------------
-template <int NV>  // float4 per lane: supports D <= NV*256
+template <int NV, bool F32OUT = false>  // float4 per lane: supports D <= NV*256; F32OUT: y is float* (final norms)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                         int M, int D, float eps) {
@@ -47,11 +47,45 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         if (c < D) {
             const f32x4 g = *(const f32x4*)(gamma + c);
             const f32x4 b = *(const f32x4*)(beta + c);
-            uint2 p;
-            p.x = pack_bf2((v[i][0] - mean) * rstd * g[0] + b[0], (v[i][1] - mean) * rstd * g[1] + b[1]);
-            p.y = pack_bf2((v[i][2] - mean) * rstd * g[2] + b[2], (v[i][3] - mean) * rstd * g[3] + b[3]);
-            *(uint2*)(yr + c) = p;
+            if constexpr (F32OUT) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+                *(f32x4*)((float*)y + (size_t)row * D + c) = o;
+            } else {
+                uint2 p;
+                p.x = pack_bf2((v[i][0] - mean) * rstd * g[0] + b[0], (v[i][1] - mean) * rstd * g[1] + b[1]);
+                p.y = pack_bf2((v[i][2] - mean) * rstd * g[2] + b[2], (v[i][3] - mean) * rstd * g[3] + b[3]);
+                *(uint2*)(yr + c) = p;
+            }
         }
+    }
+}
+
+// CLIP text embeddings (HF CLIPTextEmbeddings: token_embedding[ids] + position_embedding[0..L-1]); one block per token.
+__global__ __launch_bounds__(256) void table_embed_kernel(const int* __restrict__ ids, const float* __restrict__ tok_table,
+                                                          const float* __restrict__ pos_table, float* __restrict__ out,
+                                                          int L, int D, int vocab) {
+    const int row = blockIdx.x;
+    int id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);          // validated on the host; clamp keeps the read in range
+    const float* tr = tok_table + (size_t)id * D;
+    const float* pr = pos_table + (size_t)(row % L) * D;
+    for (int d = threadIdx.x * 4; d < D; d += 1024)
+        *(f32x4*)(out + (size_t)row * D + d) = *(const f32x4*)(tr + d) + *(const f32x4*)(pr + d);
+}
+
+// quick-GELU x * sigmoid(1.702 x) (HF activations.QuickGELUActivation, CLIP's MLP), bf16 in place
+__global__ __launch_bounds__(256) void quick_gelu_kernel(bf16_t* __restrict__ x, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        uint2 q = *(uint2*)(x + 4 * i);
+        float v[4] = {__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
+                      __uint_as_float(q.y & 0xffff0000u)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
+        q.x = pack_bf2(v[0], v[1]);
+        q.y = pack_bf2(v[2], v[3]);
+        *(uint2*)(x + 4 * i) = q;
     }
 }
 
@@ -568,6 +602,39 @@ extern "C" int uspace_layernorm_f32_bf16(const float* x, const float* gamma, con
     else if (D <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, M, D, eps);
     else if (D <= 2048) hipLaunchKernelGGL(layernorm_kernel<8>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, M, D, eps);
     else hipLaunchKernelGGL(layernorm_kernel<16>, dim3(grid), dim3(256), 0, s, x, gamma, beta, y, M, D, eps);
+    US_CHECK_LAUNCH();
+    return USPACE_OK;
+}
+
+extern "C" int uspace_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int M, int D,
+                                    float eps, uspace_stream_t stream) {
+    if (!x || !gamma || !beta || !y || M <= 0 || D <= 0 || (D & 3) || D > 4096) return USPACE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = us_cdiv(M, 4);
+    bf16_t* yy = (bf16_t*)y;
+    if (D <= 256) hipLaunchKernelGGL((layernorm_kernel<1, true>), dim3(grid), dim3(256), 0, s, x, gamma, beta, yy, M, D, eps);
+    else if (D <= 512) hipLaunchKernelGGL((layernorm_kernel<2, true>), dim3(grid), dim3(256), 0, s, x, gamma, beta, yy, M, D, eps);
+    else if (D <= 1024) hipLaunchKernelGGL((layernorm_kernel<4, true>), dim3(grid), dim3(256), 0, s, x, gamma, beta, yy, M, D, eps);
+    else if (D <= 2048) hipLaunchKernelGGL((layernorm_kernel<8, true>), dim3(grid), dim3(256), 0, s, x, gamma, beta, yy, M, D, eps);
+    else hipLaunchKernelGGL((layernorm_kernel<16, true>), dim3(grid), dim3(256), 0, s, x, gamma, beta, yy, M, D, eps);
+    US_CHECK_LAUNCH();
+    return USPACE_OK;
+}
+
+extern "C" int uspace_table_embed(const int* ids, const float* tok_table, const float* pos_table, float* out, int B, int L,
+                                  int D, int vocab, uspace_stream_t stream) {
+    if (!ids || !tok_table || !pos_table || !out || B <= 0 || L <= 0 || D <= 0 || (D & 3) || vocab <= 0) return USPACE_ERR_ARG;
+    hipLaunchKernelGGL(table_embed_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, ids, tok_table, pos_table, out, L, D,
+                       vocab);
+    US_CHECK_LAUNCH();
+    return USPACE_OK;
+}
+
+extern "C" int uspace_quick_gelu_bf16(uint16_t* x, long n, uspace_stream_t stream) {
+    if (!x || n <= 0 || (n & 3)) return USPACE_ERR_ARG;
+    const long n4 = n >> 2;
+    long gsz = (n4 + 255) / 256;
+    hipLaunchKernelGGL(quick_gelu_kernel, dim3((unsigned)(gsz > 4096 ? 4096 : gsz)), dim3(256), 0, (hipStream_t)stream, x, n4);
     US_CHECK_LAUNCH();
     return USPACE_OK;
 }

@@ -439,11 +439,6 @@ VaeWs plan_vae_ws(const uspace_vae_config& c, const VaeModel& m, int B) {
     return w;
 }
 
-#define US_TRY(expr)                        \
-    do {                                    \
-        int rc__ = (expr);                  \
-        if (rc__ != USPACE_OK) return rc__; \
-    } while (0)
 
 }  // namespace
 
