@@ -14,6 +14,7 @@
 //     ends up with 4 consecutive output columns n for one row m: bias / residual / stores
 //     are 16-byte (fp32) or 8-byte (bf16) vectors along N;
 //   * workgroup ids are remapped so that each XCD (private L2) owns a contiguous run of tiles.
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -456,33 +457,48 @@ inline GemmArgs row_slice(const GemmArgs& a, int m_lo, int m_hi) {
 
 template <int FLAGS>
 int dispatch_tile(const GemmArgs& a, hipStream_t s) {
-    // 256x256 tiles (8 waves, ~130 KiB LDS, 1 workgroup/CU) when they fill the 256 CUs at least
-    // once; otherwise 128x128 tiles (4 waves, ~66 KiB LDS, 2 workgroups/CU).
+    // Three tile configurations, chosen by a round-count cost model (unit: one round of 256x256 tiles):
+    //   256x256, 8 waves, ~130 KiB LDS, 1 workgroup/CU           cost 1.00 per round of 256 tiles
+    //   192x256, 8 waves, ~112 KiB LDS, 1 workgroup/CU           cost 0.78 (3/4 of the work, same fixed costs)
+    //   128x128, 4 waves,  ~66 KiB LDS, 2 workgroups/CU          cost 0.55 per round of 512 tiles
+    // plus the split form: whole rounds of 256x256 tiles and the remaining rows as one round of 128x128 tiles (rows
+    // are independent, so it is two launches).  Extra-strip plans (plan_rows) cost 1/16 more per round.
+    // Examples: U-ViT-L B=64 (M=16448): every shape -> 256x256 in exactly 3 / 1 / 4 / 1 / 1 rounds;
+    // U-ViT-S T2I B=64 (M=21376, N=512): 128x128 needs 668 tiles = 1.3 rounds of 512 -> 192x256: 222 tiles, one round.
     const int tn = us_cdiv(a.N, 256);
     const long big_tiles = (long)(a.M / 256) * tn;
-    if (big_tiles < 256 || a.N <= 128) return launch<128, 128, 2, 2, FLAGS>(a, s, 512);   // N <= 128: no half-empty 256-wide tiles
-    // Wave quantisation: when the last round of 256x256 tiles would be mostly empty (e.g. T2I, M = 64*334,
-    // N = 1024: 320 tiles = 1.25 rounds), run whole rounds with big tiles and the remaining rows as one
-    // round of 128x128 tiles (2 per CU, ~0.55 of a big round) -- rows are independent, so it is two launches.
-    const Plan p = plan_rows(a.M, 256, tn, 256);
-    const int rounds = us_cdiv(p.tiles_m * tn, 256);
-    const double single = rounds * (p.xrows > 0 ? 1.0625 : 1.0);
+    auto strip = [](const Plan& p) { return p.xrows > 0 ? 1.0625 : 1.0; };
+    const Plan ps = plan_rows(a.M, 128, us_cdiv(a.N, 128), 512);
+    const long st = (long)ps.tiles_m * us_cdiv(a.N, 128);
+    const double cost_small = ((double)(st / 512) * 0.55 + (st % 512 ? (st % 512 <= 256 ? 0.33 : 0.55) : 0.0)) * strip(ps);
+    if (a.N <= 128 || a.M < 192) return launch<128, 128, 2, 2, FLAGS>(a, s, 512);   // no half-empty 256-wide tiles
+    const Plan pb = plan_rows(a.M, 256, tn, 256);
+    const double cost_big = a.M >= 256 ? us_cdiv(pb.tiles_m * tn, 256) * strip(pb) : 1e30;
+    const Plan pm = plan_rows(a.M, 192, tn, 256);
+    const double cost_mid = us_cdiv(pm.tiles_m * tn, 256) * strip(pm) * 0.78;
+    double cost_split = 1e30;
+    int m1 = 0;
     const int full_rounds = (int)(big_tiles / 256);
     if (full_rounds >= 1 && tn <= 256) {
         const int tm_full = full_rounds * 256 / tn;                  // tile rows that fill whole rounds
-        const int m1 = tm_full * 256;
+        m1 = tm_full * 256;
         const int rest = a.M - m1;
         if (rest > 0 && tm_full * tn == full_rounds * 256) {
             const long small_tiles = (long)us_cdiv(rest, 128) * us_cdiv(a.N, 128);
-            const double split = full_rounds + 0.55 * (double)us_cdiv((int)small_tiles, 512) + 0.06;
-            if (small_tiles <= 512 && split < single - 0.05) {
-                int rc = launch<256, 256, 2, 4, FLAGS>(row_slice(a, 0, m1), s, 256);
-                if (rc != USPACE_OK) return rc;
-                return launch<128, 128, 2, 2, FLAGS>(row_slice(a, m1, a.M), s, 512);
-            }
+            if (small_tiles <= 512) cost_split = full_rounds + 0.55 * (double)us_cdiv((int)small_tiles, 512) + 0.06;
         }
     }
-    return launch<256, 256, 2, 4, FLAGS>(a, s, 256);
+    const double best = std::min(std::min(cost_big, cost_mid), std::min(cost_small, cost_split));
+    if (best == cost_big || (cost_split < 1e29 && cost_split >= cost_big - 0.05 && best == cost_split)) {
+        if (cost_big < 1e29) return launch<256, 256, 2, 4, FLAGS>(a, s, 256);
+    }
+    if (best == cost_split) {
+        int rc = launch<256, 256, 2, 4, FLAGS>(row_slice(a, 0, m1), s, 256);
+        if (rc != USPACE_OK) return rc;
+        return launch<128, 128, 2, 2, FLAGS>(row_slice(a, m1, a.M), s, 512);
+    }
+    if (best == cost_mid) return launch<192, 256, 2, 4, FLAGS>(a, s, 256);
+    return launch<128, 128, 2, 2, FLAGS>(a, s, 512);
 }
 
 int dispatch_flags(const GemmArgs& g, int epi_flags, hipStream_t s) {
