@@ -60,6 +60,10 @@ USPACE_API int uspace_gemm_bf16(const uint16_t* A, int lda, const uint16_t* A2, 
                      float* out_f32, int ld_f32, uint16_t* out_bf16, int ld_bf16,
                      uspace_stream_t stream);
 
+/* Which tile configuration uspace_gemm_bf16 uses for an [M, N] output (host-side planning, no GPU work):
+ * 0 = 256x256 tiles, 1 = 192x256, 2 = 128x128, 3 = rows [0, *split_rows) as 256x256 and the rest as 128x128. */
+USPACE_API int uspace_gemm_tile_choice(int M, int N, int* split_rows);
+
 /* Sum of row-shifted GEMMs:  acc[m, n] = sum_t A[m + row_shift[t], 0:K1] . W[n, t*K1:(t+1)*K1]  (+ epilogue
  * as above).  With rows = pixels of a zero-bordered NHWC map [B, H+2, W+2, C] and the 9 shifts
  * dy*(W+2)+dx this is Conv2d(C, N, 3, padding=1) (libs/autoencoder.py:85-112); the caller provides

@@ -414,3 +414,21 @@ def test_clip_module_surface(golden_dir):
     assert get_word_inds("a dog running fast", "running", Tok()).tolist() == [3, 4]
     assert get_word_inds("a dog running fast", 3, Tok()).tolist() == [5]
     assert get_word_inds("a dog running fast", "cat", Tok()).tolist() == []
+
+
+def test_gemm_tile_planning_on_headline_shapes():
+    """uspace_gemm_tile_choice: the U-ViT-L B=64 shapes stay on the measured 256x256 form (3 / 1 / 4 / 1 / 1 rounds);
+    narrow outputs and short row counts go to smaller tiles."""
+    from uspace_amd import _hip
+    L = _hip.lib()
+
+    def choice(M, N):
+        s = ctypes.c_int(0)
+        return L.uspace_gemm_tile_choice(M, N, ctypes.byref(s)), s.value
+    for N in (1024, 3072, 4096):
+        assert choice(64 * 257, N)[0] == 0
+    assert choice(64 * 334, 512)[0] == 1            # U-ViT-S T2I: 224 tiles of 192x256 = one round instead of 1.3
+    assert choice(4 * 257, 1536)[0] == 2 and choice(300, 64)[0] == 2 and choice(16448, 128)[0] == 2
+    c, rows = choice(64 * 334, 1024)
+    assert c in (1, 3) and (c != 3 or (0 < rows < 64 * 334 and rows % 256 == 0))
+    assert L.uspace_gemm_tile_choice(0, 64, None) < 0

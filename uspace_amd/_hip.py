@@ -50,6 +50,7 @@ _P, _I, _L, _F, _SZ = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_flo
 SIGNATURES = {
     "uspace_abi_version": (_I, []),
     "uspace_gemm_bf16": (_I, [_P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I, _P]),
+    "uspace_gemm_tile_choice": (_I, [_I, _I, ctypes.POINTER(_I)]),
     "uspace_gemm_slabs_bf16": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, ctypes.POINTER(_I), _I, _P, _P, _I, _P, _I, _P, _I, _P]),
     "uspace_layernorm_f32_bf16": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     "uspace_attention_bf16": (_I, [_P, _P, _P, _I, _I, _I, _P]),

@@ -455,27 +455,30 @@ inline GemmArgs row_slice(const GemmArgs& a, int m_lo, int m_hi) {
     return g;
 }
 
-template <int FLAGS>
-int dispatch_tile(const GemmArgs& a, hipStream_t s) {
-    // Three tile configurations, chosen by a round-count cost model (unit: one round of 256x256 tiles):
-    //   256x256, 8 waves, ~130 KiB LDS, 1 workgroup/CU           cost 1.00 per round of 256 tiles
-    //   192x256, 8 waves, ~112 KiB LDS, 1 workgroup/CU           cost 0.78 (3/4 of the work, same fixed costs)
-    //   128x128, 4 waves,  ~66 KiB LDS, 2 workgroups/CU          cost 0.55 per round of 512 tiles
-    // plus the split form: whole rounds of 256x256 tiles and the remaining rows as one round of 128x128 tiles (rows
-    // are independent, so it is two launches).  Extra-strip plans (plan_rows) cost 1/16 more per round.
-    // Examples: U-ViT-L B=64 (M=16448): every shape -> 256x256 in exactly 3 / 1 / 4 / 1 / 1 rounds;
-    // U-ViT-S T2I B=64 (M=21376, N=512): 128x128 needs 668 tiles = 1.3 rounds of 512 -> 192x256: 222 tiles, one round.
+enum TileChoice { TILE_BIG = 0, TILE_MID = 1, TILE_SMALL = 2, TILE_SPLIT = 3 };
+
+// Three tile configurations, chosen by a round-count cost model (unit: one round of 256x256 tiles):
+//   256x256, 8 waves, ~130 KiB LDS, 1 workgroup/CU           cost 1.00 per round of 256 tiles
+//   192x256, 8 waves, ~112 KiB LDS, 1 workgroup/CU           cost 0.80 (3/4 of the work, same fixed costs)
+//   128x128, 4 waves,  ~66 KiB LDS, 2 workgroups/CU          cost 0.55 per round of 512 tiles
+// plus the split form: whole rounds of 256x256 tiles and the remaining rows as one round of 128x128 tiles (rows
+// are independent, so it is two launches).  Extra-strip plans (plan_rows) cost one more 16-row MFMA tile per workgroup.
+// Examples: U-ViT-L B=64 (M=16448): every shape -> 256x256 in exactly 3 / 1 / 4 / 1 / 1 rounds;
+// U-ViT-S T2I B=64 (M=21376, N=512): 128x128 needs 668 tiles = 1.3 rounds of 512 -> 192x256: 224 tiles, one round.
+TileChoice choose_tile(int M, int N, int* split_rows) {
+    struct { int M, N; } a{M, N};
+    *split_rows = 0;
+    if (a.N <= 128 || a.M < 192) return TILE_SMALL;   // no half-empty 256-wide tiles
     const int tn = us_cdiv(a.N, 256);
     const long big_tiles = (long)(a.M / 256) * tn;
-    auto strip = [](const Plan& p) { return p.xrows > 0 ? 1.0625 : 1.0; };
+    auto strip = [](const Plan& p, int bm) { return p.xrows > 0 ? 1.0 + 16.0 / bm : 1.0; };   // one more 16-row MFMA tile per workgroup
     const Plan ps = plan_rows(a.M, 128, us_cdiv(a.N, 128), 512);
     const long st = (long)ps.tiles_m * us_cdiv(a.N, 128);
-    const double cost_small = ((double)(st / 512) * 0.55 + (st % 512 ? (st % 512 <= 256 ? 0.33 : 0.55) : 0.0)) * strip(ps);
-    if (a.N <= 128 || a.M < 192) return launch<128, 128, 2, 2, FLAGS>(a, s, 512);   // no half-empty 256-wide tiles
+    const double cost_small = ((double)(st / 512) * 0.55 + (st % 512 ? (st % 512 <= 256 ? 0.33 : 0.55) : 0.0)) * strip(ps, 128);
     const Plan pb = plan_rows(a.M, 256, tn, 256);
-    const double cost_big = a.M >= 256 ? us_cdiv(pb.tiles_m * tn, 256) * strip(pb) : 1e30;
+    const double cost_big = a.M >= 256 ? us_cdiv(pb.tiles_m * tn, 256) * strip(pb, 256) : 1e30;
     const Plan pm = plan_rows(a.M, 192, tn, 256);
-    const double cost_mid = us_cdiv(pm.tiles_m * tn, 256) * strip(pm) * 0.78;
+    const double cost_mid = us_cdiv(pm.tiles_m * tn, 256) * strip(pm, 192) * 0.80;
     double cost_split = 1e30;
     int m1 = 0;
     const int full_rounds = (int)(big_tiles / 256);
@@ -488,17 +491,29 @@ int dispatch_tile(const GemmArgs& a, hipStream_t s) {
             if (small_tiles <= 512) cost_split = full_rounds + 0.55 * (double)us_cdiv((int)small_tiles, 512) + 0.06;
         }
     }
-    const double best = std::min(std::min(cost_big, cost_mid), std::min(cost_small, cost_split));
-    if (best == cost_big || (cost_split < 1e29 && cost_split >= cost_big - 0.05 && best == cost_split)) {
-        if (cost_big < 1e29) return launch<256, 256, 2, 4, FLAGS>(a, s, 256);
-    }
+    // the 256x256 form is the measured one on the headline shapes: the others must beat it by a clear margin
+    const double best = std::min(std::min(cost_big * 0.93, cost_mid), std::min(cost_small, cost_split));
+    if (best == cost_big * 0.93) return TILE_BIG;
     if (best == cost_split) {
-        int rc = launch<256, 256, 2, 4, FLAGS>(row_slice(a, 0, m1), s, 256);
-        if (rc != USPACE_OK) return rc;
-        return launch<128, 128, 2, 2, FLAGS>(row_slice(a, m1, a.M), s, 512);
+        *split_rows = m1;
+        return TILE_SPLIT;
     }
-    if (best == cost_mid) return launch<192, 256, 2, 4, FLAGS>(a, s, 256);
-    return launch<128, 128, 2, 2, FLAGS>(a, s, 512);
+    return best == cost_mid ? TILE_MID : TILE_SMALL;
+}
+
+template <int FLAGS>
+int dispatch_tile(const GemmArgs& a, hipStream_t s) {
+    int m1 = 0;
+    switch (choose_tile(a.M, a.N, &m1)) {
+        case TILE_BIG: return launch<256, 256, 2, 4, FLAGS>(a, s, 256);
+        case TILE_MID: return launch<192, 256, 2, 4, FLAGS>(a, s, 256);
+        case TILE_SPLIT: {
+            int rc = launch<256, 256, 2, 4, FLAGS>(row_slice(a, 0, m1), s, 256);
+            if (rc != USPACE_OK) return rc;
+            return launch<128, 128, 2, 2, FLAGS>(row_slice(a, m1, a.M), s, 512);
+        }
+        default: return launch<128, 128, 2, 2, FLAGS>(a, s, 512);
+    }
 }
 
 int dispatch_flags(const GemmArgs& g, int epi_flags, hipStream_t s) {
@@ -518,6 +533,14 @@ int dispatch_flags(const GemmArgs& g, int epi_flags, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int uspace_gemm_tile_choice(int M, int N, int* split_rows) {
+    int m1 = 0;
+    if (M <= 0 || N <= 0) return USPACE_ERR_ARG;
+    const int c = (int)choose_tile(M, N, &m1);
+    if (split_rows) *split_rows = m1;
+    return c;
+}
 
 extern "C" int uspace_gemm_bf16(const uint16_t* A, int lda, const uint16_t* A2, int lda2, int K1,
                                 const uint16_t* W, int ldw, int M, int N, int K, int epi_flags,
