@@ -123,6 +123,15 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the auxiliary Euler-50 measurement")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: re-launch as one rank per GPU (what the driver does itself)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                                   f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                                   os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
