@@ -246,3 +246,24 @@ def test_hipgraph_replay_is_bit_identical_to_eager(golden_dir):
     h, _ = net(x, expand_t(0.3, 3), context=ctx, dissect_name="p2p", fm_direction="decode", t_edit=0.5, block_id="all",
                target_context_ids=ids, token_kwargs=dict(token_dissect="p2p_rescale", p2p_multiplier=3.0))
     assert bool(torch.isfinite(h).all())
+
+
+def test_empty_single_and_ragged_batches(golden_dir):
+    """Edge cases of the batch dimension: B = 0 (the reference returns an empty prediction), B = 1, and a batch whose
+    row count is not a multiple of any tile (rows are independent: each row equals its single-row evaluation)."""
+    zt, sd = load_sd(golden_dir, "tiny_u.npz")
+    net = build("uvit", sd, num_classes=-1, **TINY)
+    x = dev(zt["x"])
+    out0, aux = net(x[:0], expand_t(0.3, 0), None, edit_loc=None)
+    assert aux is None and out0.shape == (0, 4, 16, 16)
+    g = torch.Generator().manual_seed(3)
+    big = torch.randn(7, 4, 16, 16, generator=g).cuda()
+    net.use_graph = False
+    full, _ = net(big, expand_t(0.3, 7), None, edit_loc=None)
+    for i in (0, 3, 6):
+        one, _ = net(big[i:i + 1].contiguous(), expand_t(0.3, 1), None, edit_loc=None)
+        assert rel_l2(one.cpu().numpy(), full[i:i + 1].cpu().numpy()) < 2e-3
+    from uspace_amd.flow_matching import CNF
+    z = CNF(net).decode(x[:0], None, dissect_name="none", edit_loc=None,
+                        solver_kwargs=dict(solver="fixed", solver_fix="euler", solver_fix_step=0.5))
+    assert z.shape == (0, 4, 16, 16)

@@ -263,6 +263,8 @@ class UViTBase(nn.Module):
             raise ValueError(f"x must be [B,{self.in_chans},{self.img_size},{self.img_size}], got {tuple(x.shape)}")
         B = x.shape[0]
         dev = x.device
+        if B == 0:                                  # empty batch: the reference returns an empty prediction
+            return torch.empty(0, self.in_chans, self.img_size, self.img_size, dtype=x.dtype, device=dev)
         xin = x.detach().to(torch.float32).contiguous()
         t = timesteps
         if not torch.is_tensor(t):

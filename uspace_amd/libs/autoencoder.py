@@ -175,6 +175,8 @@ class FrozenAutoencoderKL(nn.Module):
         if z.dim() != 4 or z.shape[1] != self.z_channels or z.shape[2] != self.z_res or z.shape[3] != self.z_res:
             raise ValueError(f"z must be [B,{self.z_channels},{self.z_res},{self.z_res}], got {tuple(z.shape)}")
         dev = z.device
+        if z.shape[0] == 0:
+            return torch.empty(0, self.out_ch, self.resolution, self.resolution, dtype=z.dtype, device=dev)
         blob = self._packed_blob(dev)
         L = _hip.lib()
         zin = z.detach().to(torch.float32).contiguous()

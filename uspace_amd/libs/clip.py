@@ -150,6 +150,8 @@ class CLIPTextTransformer(nn.Module):
         if input_ids.numel() and (int(input_ids.min()) < 0 or int(input_ids.max()) >= self.cfg["vocab"]):
             raise IndexError("token id out of range")            # nn.Embedding raises IndexError as well
         dev = input_ids.device
+        if input_ids.shape[0] == 0 or input_ids.shape[1] == 0:
+            return torch.empty(input_ids.shape[0], input_ids.shape[1], self.cfg["dim"], dtype=torch.float32, device=dev)
         blob = self._packed_blob(dev)
         L = _hip.lib()
         cfg = self._c_cfg()

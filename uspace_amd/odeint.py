@@ -147,6 +147,10 @@ def odeint(func, y0, t0, t1, *, method="dopri5", rtol=1e-5, atol=1e-5, step_size
                               rejection ("dopri5-50" of BASELINE.md: 1 + 6*n NFE)
     """
     stats = stats if stats is not None else Stats()
+    if hasattr(y0, "numel") and y0.numel() == 0:      # empty batch: nothing to integrate (torchdiffeq returns y0's shape)
+        if method not in FIXED and method not in ADAPTIVE:
+            raise NotImplementedError(f"method={method}")
+        return y0.clone()
     if ops is None:
         ops = HipStateOps(y0)
     y = ops.prepare(y0)
