@@ -306,3 +306,33 @@ def test_output_head_matches_oracle(hip, B, D, extras):
     assert rc == 0
     got = out.cpu().numpy()
     assert np.abs(got - ref).max() <= 3e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("M,N,K,expect", [
+    (64 * 334, 512, 128, 1),      # U-ViT-S T2I rows: 192x256 tiles (224 of them, one round), extra strips unused
+    (16448, 1536, 64, 1),         # 192x256 with extra strips (80 tile rows + 14-row strips)
+    (64 * 334, 1024, 64, None),   # U-ViT-L T2I proj/fc2 shape: 192x256 or the 256x256 + 128x128 split
+    (16448, 1024, 64, 0),         # the headline shape: 256x256 with extra strips
+])
+def test_gemm_tile_configurations_at_full_row_counts(hip, M, N, K, expect):
+    """Every tile configuration the planner can pick at BASELINE row counts, with the fused proj/fc2 epilogue
+    (bias + residual in place + bf16 copy); checked against the oracle on a sample of rows incl. the last ones."""
+    import ctypes
+    split = ctypes.c_int(0)
+    choice = hip.lib().uspace_gemm_tile_choice(M, N, ctypes.byref(split))
+    assert expect is None or choice == expect, (choice, split.value)
+    rng = np.random.default_rng(M + N)
+    A = bf16_round(_rand(rng, M, K))
+    W = bf16_round(_rand(rng, N, K) * 0.1)
+    b = _rand(rng, N)
+    R = _rand(rng, M, N)
+    x = to_dev(R).clone()
+    xb = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    hip.gemm(to_dev(A, torch.bfloat16), to_dev(W, torch.bfloat16), bias=to_dev(b), resid=x, out_f32=x, out_bf16=xb)
+    rows = np.unique(np.concatenate([rng.integers(0, M, 1500), np.arange(M - 300, M), np.arange(0, 300),
+                                     np.arange(max(split.value - 150, 0), min(split.value + 150, M))]))
+    ref = C.linear(A[rows], W, b) + R[rows]
+    got = x.cpu().numpy()[rows]
+    np.testing.assert_allclose(got, ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
+    assert rel_l2(got, ref) < 1e-5
+    assert torch.equal(xb, x.to(torch.bfloat16))
