@@ -19,6 +19,7 @@ What is pinned:
   p2p_t2i                           tools/utils_t2i.py:265 attention-map hook
   attr_directions                   tools/utils_attr.py:124 mean(pos) - mean(neg) attribute directions
   vae_decoder_tiny                  libs/autoencoder.py:303-409,446-450 SD-VAE decoder, tiny config + taps
+  pca_components                    tools/utils_vis.py:80-118 sklearn PCA directions for the write_pca hook
   clip_text_tiny                    libs/clip.py:40-91 CLIP text transformer (HF CLIPTextModel), tiny config + hidden states
   big_{S,L}_{u,t}                   seed-regenerated weights (sha256 pinned) -> out, B=2
   euler20_S_u                       BASELINE config 1: 20 fixed Euler steps, B=4, driven by
@@ -432,6 +433,22 @@ def make_vae_decoder():
     save("vae_decoder_tiny.npz", **out)
 
 
+def make_pca_components():
+    """tools/utils_vis.py:80-118 get_pca_components_sklearn (sklearn PCA, svd_solver="full") on synthetic activations:
+    the principal directions the ``write_pca`` hook consumes (``pca{n}_{t}.npy``, tools/utils_pca.py:13-50;
+    SURVEY.md 8(f) rank 3)."""
+    import importlib
+    uv = importlib.import_module("tools.utils_vis")
+    rng = np.random.default_rng(9)
+    N, shape, n = 48, (4, 6, 6), 6
+    basis = rng.standard_normal((10,) + shape).astype(np.float32)
+    coef = rng.standard_normal((N, 10)).astype(np.float32) * np.linspace(5.0, 0.5, 10, dtype=np.float32)   # distinct spectrum
+    feats = np.einsum("nk,kchw->nchw", coef, basis) + 0.05 * rng.standard_normal((N,) + shape).astype(np.float32) + 0.7
+    comps = uv.get_pca_components_sklearn(torch.from_numpy(feats), n_components=n).numpy()
+    save("pca_components.npz", feats=feats.astype(np.float32), components=comps.astype(np.float32),
+         n_components=np.array(n))
+
+
 def make_clip_text():
     """libs/clip.py:40-91 FrozenCLIPEmbedder.forward = HF ``CLIPTextModel(input_ids=tokens).last_hidden_state``.
     The pretrained weights and the tokenizer files are not in the image, so the fixture is the same HF module
@@ -466,11 +483,16 @@ def make_clip_text():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-large", action="store_true")
+    ap.add_argument("--only-pca", action="store_true", help="regenerate only pca_components.npz")
     ap.add_argument("--only-clip", action="store_true", help="regenerate only clip_text_tiny.npz (no reference import needed)")
     args = ap.parse_args()
     if args.only_clip:
         torch.set_grad_enabled(False)
         make_clip_text()
+        return
+    if args.only_pca:
+        _refshim.load_reference()
+        make_pca_components()
         return
     uvit, uvit_t2i = _refshim.load_reference()
     torch.set_grad_enabled(False)
@@ -481,6 +503,7 @@ def main():
     make_p2p_t2i(mt, xt, ctx)
     make_attr_directions()
     make_vae_decoder()
+    make_pca_components()
     make_clip_text()
     if not args.skip_large:
         timing = dict(threads=torch.get_num_threads(), nproc=os.cpu_count(),

@@ -240,3 +240,33 @@ def test_read_hook_feeds_accumulator_then_write_hook_uses_it(golden_dir):
         edited = cnf.decode(x0, None, write_scale=2.0, **kw)
         plain = cnf.decode(x0, None, write_scale=0.0, **kw)
         assert bool(torch.isfinite(edited).all()) and rel_l2(edited.cpu().numpy(), plain.cpu().numpy()) > 1e-4
+
+
+def test_pca_directions_on_device_match_reference_golden(golden_dir, tmp_path):
+    """tools/utils_pca.py:13-50 / tools/utils_vis.py:80-118: principal directions of tapped activations (Gram-matrix
+    route on the device) against the reference function's output, from tensors, from the accumulator the read hook can
+    feed, and from ``{batch_id}_{t}.npy`` files; the result is what the write_pca hook loads."""
+    from uspace_amd.tools.utils_pca import PcaAccumulator, extract_hspace_feat_unet_by_pca, pca_components
+    z = np.load(os.path.join(golden_dir, "pca_components.npz"))
+    feats, ref, n = z["feats"], z["components"], int(z["n_components"])
+
+    def same_up_to_sign(got):
+        assert got.shape == ref.shape
+        for g, r in zip(got.reshape(n, -1), ref.reshape(n, -1)):
+            assert abs(abs(float(np.dot(g, r))) - 1.0) < 1e-4 and np.abs(g * np.sign(np.dot(g, r)) - r).max() < 2e-4
+    x = torch.from_numpy(feats).cuda()
+    got = pca_components(x, n)
+    same_up_to_sign(got.cpu().numpy())
+    gram = got.reshape(n, -1) @ got.reshape(n, -1).t()
+    assert float((gram - torch.eye(n, device="cuda")).abs().max()) < 1e-4          # orthonormal
+    acc = PcaAccumulator()
+    for lo in range(0, len(feats), 16):
+        acc.update("0.30", x[lo:lo + 16])
+    assert acc.finalize(str(tmp_path), n) == ["0.30"]
+    same_up_to_sign(np.load(tmp_path / f"pca{n}_0.30.npy"))
+    for b, lo in enumerate(range(0, len(feats), 16)):
+        np.save(tmp_path / f"{b}_0.50.npy", feats[lo:lo + 16])
+    assert "0.50" in extract_hspace_feat_unet_by_pca(str(tmp_path), n_components=n, batch_num=3)
+    same_up_to_sign(np.load(tmp_path / f"pca{n}_0.50.npy"))
+    with pytest.raises(ValueError):
+        pca_components(x, len(feats) + 1)

@@ -167,3 +167,16 @@ def test_clip_text_oracle_matches_hf_module(golden_dir):
     for i, h in enumerate(hidden):
         np.testing.assert_allclose(h, z[f"hidden/{i}"], rtol=2e-4, atol=2e-5, err_msg=f"hidden {i}")
     np.testing.assert_allclose(out, z["out"], rtol=2e-4, atol=2e-5)
+
+
+def test_pca_oracle_matches_reference(golden_dir):
+    """tools/utils_vis.py:80-118 (sklearn PCA, full SVD) on the fixture activations: same directions, up to sklearn's
+    sign convention (which moved between u- and v-based across versions, so compare up to sign)."""
+    from oracle import pca_oracle as P
+    z = np.load(os.path.join(golden_dir, "pca_components.npz"))
+    got = P.pca_components(z["feats"], int(z["n_components"]))
+    ref = z["components"]
+    assert got.shape == ref.shape
+    for g, r in zip(got.reshape(len(got), -1), ref.reshape(len(ref), -1)):
+        s = np.sign(np.dot(g, r))
+        np.testing.assert_allclose(g * s, r, atol=2e-5)

@@ -109,8 +109,8 @@ def save_activation(path, tensor, kwargs=None):
     ([B, attr_dim]) in the kwargs the activation is folded into device-resident attribute sums instead of
     being written to disk (the file name's timestep part is the accumulator key)."""
     acc = kwargs.get("direction_accumulator") if kwargs else None
-    if acc is not None:
-        acc.update(os.path.basename(path).split("_")[-1], tensor, kwargs["attrs"])
+    if acc is not None:      # DirectionAccumulator (needs attrs) or tools.utils_pca.PcaAccumulator (does not)
+        acc.update(os.path.basename(path).split("_")[-1], tensor, kwargs.get("attrs"))
         return
     os.makedirs(os.path.dirname(path), exist_ok=True)
     np.save(path, tensor.detach().cpu().numpy())
