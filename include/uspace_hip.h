@@ -45,6 +45,8 @@ USPACE_API int uspace_abi_version(void);
 #define USPACE_EPI_RESIDUAL 4    /* + resid_in[M,N] (fp32)                      */
 #define USPACE_EPI_OUT_F32 8     /* write out_f32[M,N]                          */
 #define USPACE_EPI_OUT_BF16 16   /* write out_bf16[M,N]                         */
+#define USPACE_EPI_CEN_OUT 32    /* uspace_gemm_bf16_ext: also write bf16(v - row_c[m]) and per-row partial sums */
+#define USPACE_EPI_LN_IN 64      /* uspace_gemm_bf16_ext: A holds centred rows; apply LayerNorm through the GEMM  */
 
 /* nn.Linear on bf16 operands with fp32 accumulation on the MFMA cores:
  *     acc[M,N] = [A | A2][M,K] . W[N,K]^T
@@ -59,6 +61,36 @@ USPACE_API int uspace_gemm_bf16(const uint16_t* A, int lda, const uint16_t* A2, 
                      const float* bias, const float* resid_in, int ld_resid,
                      float* out_f32, int ld_f32, uint16_t* out_bf16, int ld_bf16,
                      uspace_stream_t stream);
+
+/* LayerNorm folded through the GEMMs that surround it (no separate LayerNorm pass over the residual stream).
+ *   y = LN(x) W^T + b = rstd * ((x - mu) . (W gamma)^T) + (b + W beta)
+ * Producer of x (proj / fc2 / skip_linear, USPACE_EPI_CEN_OUT): besides its usual outputs writes out_cen[m, n] =
+ *   bf16(v[m, n] - row_c[m]) -- row_c is any per-row constant close to the row mean, so the rounding acts on centred
+ *   values exactly as it does on LayerNorm's output today -- and part_out[m][tile][2] = (sum, sum of squares) of
+ *   v - row_c over each N tile (uspace_gemm_part_slots(M, N) tiles per row; fixed summation order, no atomics).
+ * Consumer (qkv / fc1, USPACE_EPI_LN_IN): A = out_cen, W = bf16(W * gamma), bias = b + W beta, colsum[n] = sum_k of the
+ *   bf16 W rows; from part_in it derives d = mean(v - row_c), rstd = 1/sqrt(var + eps) (norm_dim = row length) and
+ *   applies y = rstd * (acc - d * colsum) + bias before the rest of the epilogue; with c_out it also publishes
+ *   c_out[m] = row_c[m] + d (the row mean) for the next producer. */
+typedef struct uspace_gemm_ext {
+    const float* row_c;     /* [M]   CEN_OUT: centring constants; LN_IN: the ones its producer used (only with c_out) */
+    uint16_t* out_cen;      /* [M, ld_cen] bf16 */
+    int ld_cen;
+    float* part_out;        /* [M][uspace_gemm_part_slots(M, N)][2] */
+    const float* part_in;   /* [M][np_in][2] */
+    int np_in;
+    const float* colsum;    /* [N] */
+    float* c_out;           /* [M] or NULL */
+    int norm_dim;           /* LayerNorm width (row length of the producer's output) */
+    float eps;
+} uspace_gemm_ext;
+USPACE_API int uspace_gemm_bf16_ext(const uint16_t* A, int lda, const uint16_t* A2, int lda2, int K1,
+                                    const uint16_t* W, int ldw, int M, int N, int K, int epi_flags,
+                                    const float* bias, const float* resid_in, int ld_resid,
+                                    float* out_f32, int ld_f32, uint16_t* out_bf16, int ld_bf16,
+                                    const uspace_gemm_ext* ext, uspace_stream_t stream);
+/* number of N tiles (= partial-sum slots per row) a CEN_OUT launch with this [M, N] output uses */
+USPACE_API int uspace_gemm_part_slots(int M, int N);
 
 /* Which tile configuration uspace_gemm_bf16 uses for an [M, N] output (host-side planning, no GPU work):
  * 0 = 256x256 tiles, 1 = 192x256, 2 = 128x128, 3 = rows [0, *split_rows) as 256x256 and the rest as 128x128. */

@@ -336,3 +336,67 @@ def test_gemm_tile_configurations_at_full_row_counts(hip, M, N, K, expect):
     np.testing.assert_allclose(got, ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
     assert rel_l2(got, ref) < 1e-5
     assert torch.equal(xb, x.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("M,D,Kp,N2", [
+    (16448, 1024, 64, 1024),     # headline row count: 256x256 tiles with extra strips on both sides
+    (16448, 1024, 64, 512),      # consumer on 128x128 tiles
+    (64 * 334, 512, 64, 1536),   # U-ViT-S T2I rows: producer on 192x256 tiles
+    (515, 256, 128, 256),        # small everything, ragged rows
+])
+def test_layernorm_folded_through_gemms(hip, M, D, Kp, N2):
+    """Producer (x = A W^T + b + R, also centred bf16 copy + per-row partial sums) followed by a consumer computing
+    LN(x; gamma, beta) W2^T + b2 from the centred copy (uspace_gemm_bf16_ext), against LayerNorm + Linear of the oracle
+    (libs/uvit.py:135-161: norm1 -> qkv, norm2 -> fc1)."""
+    import ctypes
+    rng = np.random.default_rng(M + D + N2)
+    A = bf16_round(_rand(rng, M, Kp))
+    W = bf16_round(_rand(rng, D, Kp) * 0.2)
+    b = _rand(rng, D)
+    R = (_rand(rng, M, D) * 1.5 + _rand(rng, M, 1) * 2.0).astype(np.float32)      # rows with sizeable, different means
+    gam, bet = (_rand(rng, D) * 0.2 + 1.0).astype(np.float32), _rand(rng, D, scale=0.1)
+    W2 = (_rand(rng, N2, D) * 0.05).astype(np.float32)
+    b2 = _rand(rng, N2)
+    rows = np.unique(np.concatenate([rng.integers(0, M, 600), np.arange(min(M, 300)), np.arange(max(M - 300, 0), M)]))
+    x_ref = C.linear(A[rows], W, b) + R[rows]
+    y_ref = C.linear(C.layernorm(x_ref, gam, bet, eps=1e-5), W2, b2)
+    # centring constants: the row mean of a *previous* state (here: of R alone) -- close to, not equal to, the new mean
+    c = R.mean(axis=1).astype(np.float32)
+    lib = hip.lib()
+    slots = lib.uspace_gemm_part_slots(M, D)
+    assert slots in (D // 256, D // 128)
+    dA, dW, db = to_dev(A, torch.bfloat16), to_dev(W, torch.bfloat16), to_dev(b)
+    x = to_dev(R).clone()
+    xc = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+    part = torch.full((M, slots, 2), float("nan"), device="cuda")
+    dc = to_dev(c)
+    ext = hip.GemmExt(hip.ptr(dc).value, hip.ptr(xc).value, D, hip.ptr(part).value, None, 0, None, None, D, 1e-5)
+    flags = hip.EPI_BIAS | hip.EPI_RESIDUAL | hip.EPI_OUT_F32 | 32
+    rc = lib.uspace_gemm_bf16_ext(hip.ptr(dA), Kp, None, 0, Kp, hip.ptr(dW), Kp, M, D, Kp, flags, hip.ptr(db), hip.ptr(x), D,
+                                  hip.ptr(x), D, None, 0, ctypes.byref(ext), hip.stream_ptr())
+    assert rc == 0
+    xg = x.cpu().numpy()
+    np.testing.assert_allclose(xg[rows], x_ref, rtol=1e-3, atol=2e-3)
+    assert torch.equal(xc, (x - dc[:, None]).to(torch.bfloat16))
+    pg = part.cpu().numpy().astype(np.float64).sum(axis=1)
+    cen = xg.astype(np.float64) - c[:, None]
+    np.testing.assert_allclose(pg[:, 0], cen.sum(1), rtol=1e-4, atol=2e-2)
+    np.testing.assert_allclose(pg[:, 1], (cen ** 2).sum(1), rtol=1e-4)
+    # consumer: gamma folded into the weights, beta into the bias, column sums of the bf16 weights
+    W2g = bf16_round(W2 * gam[None, :])
+    bias2 = (b2 + W2 @ bet).astype(np.float32)
+    colsum = W2g.sum(axis=1).astype(np.float32)
+    y = torch.empty(M, N2, dtype=torch.bfloat16, device="cuda")
+    cout = torch.empty(M, device="cuda")
+    dW2, dbias2, dcs = to_dev(W2g, torch.bfloat16), to_dev(bias2), to_dev(colsum)
+    ext2 = hip.GemmExt(hip.ptr(dc).value, None, 0, None, hip.ptr(part).value, slots, hip.ptr(dcs).value, hip.ptr(cout).value, D,
+                       1e-5)
+    rc = lib.uspace_gemm_bf16_ext(hip.ptr(xc), D, None, 0, D, hip.ptr(dW2), D, M, N2, D, hip.EPI_BIAS | hip.EPI_OUT_BF16 | 64,
+                                  hip.ptr(dbias2), None, 0, None, 0, hip.ptr(y), N2, ctypes.byref(ext2), hip.stream_ptr())
+    assert rc == 0
+    yg = y.float().cpu().numpy()[rows]
+    assert rel_l2(yg, y_ref) < 4e-3, rel_l2(yg, y_ref)
+    np.testing.assert_allclose(cout.cpu().numpy(), xg.mean(axis=1), rtol=1e-4, atol=1e-4)
+    # the plain entry point refuses the extended flags
+    assert lib.uspace_gemm_bf16(hip.ptr(xc), D, None, 0, D, hip.ptr(dW2), D, M, N2, D, hip.EPI_OUT_BF16 | 64, None, None, 0,
+                                None, 0, hip.ptr(y), N2, hip.stream_ptr()) != 0

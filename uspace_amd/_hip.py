@@ -44,12 +44,21 @@ class ClipConfig(ctypes.Structure):
                 ("ffn", ctypes.c_int), ("max_pos", ctypes.c_int), ("eps", ctypes.c_float)]
 
 
+class GemmExt(ctypes.Structure):
+    _fields_ = [("row_c", ctypes.c_void_p), ("out_cen", ctypes.c_void_p), ("ld_cen", ctypes.c_int),
+                ("part_out", ctypes.c_void_p), ("part_in", ctypes.c_void_p), ("np_in", ctypes.c_int),
+                ("colsum", ctypes.c_void_p), ("c_out", ctypes.c_void_p), ("norm_dim", ctypes.c_int), ("eps", ctypes.c_float)]
+
+
 _P, _I, _L, _F, _SZ = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
 
 # name -> (restype, argtypes); must list every symbol include/uspace_hip.h declares
 SIGNATURES = {
     "uspace_abi_version": (_I, []),
     "uspace_gemm_bf16": (_I, [_P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I, _P]),
+    "uspace_gemm_bf16_ext": (_I, [_P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I,
+                                  ctypes.POINTER(GemmExt), _P]),
+    "uspace_gemm_part_slots": (_I, [_I, _I]),
     "uspace_gemm_tile_choice": (_I, [_I, _I, ctypes.POINTER(_I)]),
     "uspace_gemm_slabs_bf16": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, ctypes.POINTER(_I), _I, _P, _P, _I, _P, _I, _P, _I, _P]),
     "uspace_layernorm_f32_bf16": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),

@@ -35,6 +35,19 @@ struct GemmArgs {
     int n_slab, k1_log2;  // K is n_slab slabs of K1 = 2^k1_log2 (n_slab > 1); slab s reads A rows shifted by slab_shift[s]
     int slab_shift[9];    // (3x3 convolution over a zero-bordered NHWC map: 9 taps); 0 for the long-skip's second slab
     int m_main, xrows;   // XTRA: rows [m_main, M) are spread over the workgroups, xrows (<=16) each
+    // LayerNorm folded through the GEMM (DESIGN.md "LayerNorm folding"):
+    //   producer (USPACE_EPI_CEN_OUT): also writes out_cen = bf16(v - row_c[m]) and, per row and N tile, the partial
+    //                                  sums (sum, sum of squares) of v - row_c[m] to part_out[m][tiles_n][2];
+    //   consumer (USPACE_EPI_LN_IN):   A holds such centred rows; y = rstd[m] * (acc - d[m] * colsum[n]) + bias[n] with
+    //                                  d, rstd from part_in[m][np_in][2]; N tile 0 writes c_out[m] = row_c[m] + d[m].
+    const float* row_c;
+    bf16_t* out_cen;
+    float* part_out;
+    const float* part_in;
+    const float* colsum;
+    float* c_out;
+    int ld_cen, np_in;
+    float inv_d, eps;
 };
 
 constexpr int BK = 64;           // bf16 elements per K step (128 B per LDS row)
@@ -338,7 +351,31 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
             bias4[j] = *(const f32x4*)(g.bias + n);
         }
     }
-    auto emit = [&](f32x4 v, const f32x4& b, int m, int n) {
+    constexpr bool LN_IN = (FLAGS & USPACE_EPI_LN_IN) != 0, CEN = (FLAGS & USPACE_EPI_CEN_OUT) != 0;
+    f32x4 cs4[LN_IN ? TN : 1];
+    if constexpr (LN_IN) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            int n = n0 + wn * (BN / WN) + j * 16 + fq * 4;
+            n = n < g.N ? n : g.N - 4;
+            cs4[j] = *(const f32x4*)(g.colsum + n);
+        }
+    }
+    // consumer: this row's (d, rstd) from the producer's per-N-tile partial sums
+    auto row_stats = [&](int m, float& d, float& rstd) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int q = 0; q < g.np_in; ++q) {
+            const float2 pq = *(const float2*)(g.part_in + ((size_t)m * g.np_in + q) * 2);
+            s1 += pq.x;
+            s2 += pq.y;
+        }
+        d = s1 * g.inv_d;
+        rstd = rsqrtf(fmaxf(s2 * g.inv_d - d * d, 0.f) + g.eps);
+    };
+    float ps1 = 0.f, ps2 = 0.f;   // producer: running partial sums of the row being emitted
+    float row_d = 0.f, row_r = 1.f, row_cv = 0.f;
+    auto emit = [&](f32x4 v, const f32x4& b, int m, int n, const f32x4& cs) {
+        if constexpr (LN_IN) v = (v - row_d * cs) * row_r;
         if constexpr (FLAGS & USPACE_EPI_BIAS) v += b;
         if constexpr (FLAGS & USPACE_EPI_GELU) {
             v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
@@ -352,36 +389,110 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
             p.y = pack_bf2(v[2], v[3]);
             *(uint2*)(g.out_bf16 + (size_t)m * g.ld_bf16 + n) = p;
         }
+        if constexpr (CEN) {
+            const f32x4 vc = v - row_cv;
+            ps1 += (vc[0] + vc[1]) + (vc[2] + vc[3]);
+            ps2 += (vc[0] * vc[0] + vc[1] * vc[1]) + (vc[2] * vc[2] + vc[3] * vc[3]);
+            uint2 p;
+            p.x = pack_bf2(vc[0], vc[1]);
+            p.y = pack_bf2(vc[2], vc[3]);
+            *(uint2*)(g.out_cen + (size_t)m * g.ld_cen + n) = p;
+        }
+    };
+    // per-row hooks around the emits of one accumulator row (row sub-tile i of this wave / the strip row)
+    float* const red = (float*)smem;             // CEN: [BM + 16 rows][WM * WN slots][2] partials (LDS is free after the K loop)
+    constexpr int RSLOTS = WM * WN;
+    if constexpr (CEN) __syncthreads();          // every wave has finished reading the last K tile
+    auto row_begin = [&](int m, bool valid) {
+        if constexpr (LN_IN) {
+            if (valid) row_stats(m, row_d, row_r);
+        }
+        if constexpr (CEN) {
+            row_cv = valid ? g.row_c[m] : 0.f;
+            ps1 = ps2 = 0.f;
+        }
+    };
+    auto row_end = [&](int m, bool valid, int lrow, int slot) {
+        if constexpr (LN_IN) {
+            if (valid && n0 == 0 && wn == 0 && fq == 0 && g.c_out && slot >= 0) g.c_out[m] = g.row_c[m] + row_d;
+        }
+        if constexpr (CEN) {
+            float a = ps1, bq = ps2;
+            a += __shfl_xor(a, 16, 64);
+            a += __shfl_xor(a, 32, 64);
+            bq += __shfl_xor(bq, 16, 64);
+            bq += __shfl_xor(bq, 32, 64);
+            if (fq == 0) {
+                red[(lrow * RSLOTS + (slot < 0 ? -slot - 1 : slot)) * 2 + 0] = valid ? a : 0.f;
+                red[(lrow * RSLOTS + (slot < 0 ? -slot - 1 : slot)) * 2 + 1] = valid ? bq : 0.f;
+            }
+        }
     };
     const bool interior = (m0 + BM <= m_lim) && (n0 + BN <= g.N);   // workgroup-uniform
     if (interior) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + wm * (BM / WM) + i * 16 + fr;
+            row_begin(m, true);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) emit(acc[i][j], bias4[j], m, n0 + wn * (BN / WN) + j * 16 + fq * 4);
+            for (int j = 0; j < TN; ++j)
+                emit(acc[i][j], bias4[j], m, n0 + wn * (BN / WN) + j * 16 + fq * 4, cs4[LN_IN ? j : 0]);
+            row_end(m, true, wm * (BM / WM) + i * 16 + fr, wn);   // main rows: wave (wm, wn) fills slot wn of its rows
         }
     } else {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + wm * (BM / WM) + i * 16 + fr;
-            if (m >= m_lim) continue;
+            const bool vrow = m < m_lim;
+            row_begin(vrow ? m : 0, vrow);
+            if (vrow) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * (BN / WN) + j * 16 + fq * 4;
-                if (n >= g.N) continue;
-                emit(acc[i][j], bias4[j], m, n);
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * (BN / WN) + j * 16 + fq * 4;
+                    if (n >= g.N) continue;
+                    emit(acc[i][j], bias4[j], m, n, cs4[LN_IN ? j : 0]);
+                }
             }
+            row_end(m, vrow, wm * (BM / WM) + i * 16 + fr, wn);
         }
     }
     if constexpr (XTRA) {
         const int m = x0 + fr;
-        if (fr < g.xrows && m < g.M) {
+        const bool vrow = fr < g.xrows && m < g.M;
+        row_begin(vrow ? m : 0, vrow);
+        if (vrow) {
 #pragma unroll
             for (int j = 0; j < XN; ++j) {
                 const int n = n0 + wn * (BN / WN) + (wm * XN + j) * 16 + fq * 4;
-                if (n < g.N) emit(xacc[j], pick_b<WM, XN>(bias4, wm, j), m, n);
+                if (n < g.N) {
+                    f32x4 csx = cs4[0];
+                    if constexpr (LN_IN) csx = pick_b<WM, XN>(cs4, wm, j);
+                    emit(xacc[j], pick_b<WM, XN>(bias4, wm, j), m, n, csx);
+                }
             }
+        }
+        // strip rows: all WM * WN waves contribute (wave (wm, wn) holds XN of its column group's sub-tiles); only
+        // wave row 0 publishes c_out (slot >= 0), the others pass their slot as -(slot + 1)
+        row_end(m, vrow, BM + fr, wm == 0 ? wn : -(wm * WN + wn) - 1);
+    }
+    if constexpr (CEN) {
+        __syncthreads();
+        // one thread per tile row: add the slots in a fixed order and publish this N tile's partial for the row
+        for (int t = tid; t < BM + (XTRA ? 16 : 0); t += THREADS) {
+            const bool strip = t >= BM;
+            const int m = strip ? x0 + (t - BM) : m0 + t;
+            const bool ok = strip ? ((t - BM) < g.xrows && m < g.M) : (m < m_lim);
+            if (!ok) continue;
+            float a = 0.f, bq = 0.f;
+            const int nslot = strip ? RSLOTS : WN;
+#pragma unroll 1
+            for (int q = 0; q < nslot; ++q) {
+                a += red[(t * RSLOTS + q) * 2];
+                bq += red[(t * RSLOTS + q) * 2 + 1];
+            }
+            float* po = g.part_out + ((size_t)m * g.tiles_n + n0 / BN) * 2;
+            po[0] = a;
+            po[1] = bq;
         }
     }
 }
@@ -452,6 +563,12 @@ inline GemmArgs row_slice(const GemmArgs& a, int m_lo, int m_hi) {
     if (a.resid) g.resid = a.resid + (size_t)m_lo * a.ld_resid;
     if (a.out_f32) g.out_f32 = a.out_f32 + (size_t)m_lo * a.ld_f32;
     if (a.out_bf16) g.out_bf16 = a.out_bf16 + (size_t)m_lo * a.ld_bf16;
+    if (a.row_c) g.row_c = a.row_c + m_lo;
+    if (a.out_cen) g.out_cen = a.out_cen + (size_t)m_lo * a.ld_cen;
+    if (a.part_in) g.part_in = a.part_in + (size_t)m_lo * a.np_in * 2;
+    if (a.c_out) g.c_out = a.c_out + m_lo;
+    // part_out rows are indexed with the launch's own tiles_n: a split launch would mix two strides, so producers
+    // are never split (choose_tile is asked for a non-split form, see dispatch_tile)
     return g;
 }
 
@@ -504,7 +621,9 @@ TileChoice choose_tile(int M, int N, int* split_rows) {
 template <int FLAGS>
 int dispatch_tile(const GemmArgs& a, hipStream_t s) {
     int m1 = 0;
-    switch (choose_tile(a.M, a.N, &m1)) {
+    TileChoice tc = choose_tile(a.M, a.N, &m1);
+    if (tc == TILE_SPLIT && (FLAGS & USPACE_EPI_CEN_OUT)) tc = TILE_BIG;   // one partial-sum stride per launch
+    switch (tc) {
         case TILE_BIG: return launch<256, 256, 2, 4, FLAGS>(a, s, 256);
         case TILE_MID: return launch<192, 256, 2, 4, FLAGS>(a, s, 256);
         case TILE_SPLIT: {
@@ -518,7 +637,7 @@ int dispatch_tile(const GemmArgs& a, hipStream_t s) {
 
 int dispatch_flags(const GemmArgs& g, int epi_flags, hipStream_t s) {
     constexpr int B_ = USPACE_EPI_BIAS, G_ = USPACE_EPI_GELU, R_ = USPACE_EPI_RESIDUAL,
-                  F_ = USPACE_EPI_OUT_F32, H_ = USPACE_EPI_OUT_BF16;
+                  F_ = USPACE_EPI_OUT_F32, H_ = USPACE_EPI_OUT_BF16, C_ = USPACE_EPI_CEN_OUT, L_ = USPACE_EPI_LN_IN;
     switch (epi_flags) {
         case H_:                return dispatch_tile<H_>(g, s);                 // qkv
         case B_ | H_:           return dispatch_tile<B_ | H_>(g, s);
@@ -528,11 +647,24 @@ int dispatch_flags(const GemmArgs& g, int epi_flags, hipStream_t s) {
         case B_ | F_:           return dispatch_tile<B_ | F_>(g, s);            // context_embed
         case B_ | F_ | H_:      return dispatch_tile<B_ | F_ | H_>(g, s);       // skip_linear
         case F_:                return dispatch_tile<F_>(g, s);
+        // LayerNorm folded through the GEMMs (consumers LN_IN, producers CEN_OUT)
+        case L_ | B_ | H_:           return dispatch_tile<L_ | B_ | H_>(g, s);            // norm1 -> qkv
+        case L_ | B_ | G_ | H_:      return dispatch_tile<L_ | B_ | G_ | H_>(g, s);       // norm2 -> fc1 + GELU
+        case C_ | B_ | R_ | F_:      return dispatch_tile<C_ | B_ | R_ | F_>(g, s);       // proj / fc2 feeding a norm
+        case C_ | B_ | R_ | F_ | H_: return dispatch_tile<C_ | B_ | R_ | F_ | H_>(g, s);  // ... + raw bf16 copy (skip stack)
+        case C_ | B_ | F_:           return dispatch_tile<C_ | B_ | F_>(g, s);            // skip_linear feeding norm1
         default:                return USPACE_ERR_ARG;
     }
 }
 
 }  // namespace
+
+extern "C" int uspace_gemm_part_slots(int M, int N) {
+    if (M <= 0 || N <= 0) return USPACE_ERR_ARG;
+    int m1 = 0;
+    TileChoice tc = choose_tile(M, N, &m1);
+    return us_cdiv(N, tc == TILE_SMALL ? 128 : 256);     // producers never take the split form
+}
 
 extern "C" int uspace_gemm_tile_choice(int M, int N, int* split_rows) {
     int m1 = 0;
@@ -542,11 +674,11 @@ extern "C" int uspace_gemm_tile_choice(int M, int N, int* split_rows) {
     return c;
 }
 
-extern "C" int uspace_gemm_bf16(const uint16_t* A, int lda, const uint16_t* A2, int lda2, int K1,
-                                const uint16_t* W, int ldw, int M, int N, int K, int epi_flags,
-                                const float* bias, const float* resid_in, int ld_resid,
-                                float* out_f32, int ld_f32, uint16_t* out_bf16, int ld_bf16,
-                                uspace_stream_t stream) {
+extern "C" int uspace_gemm_bf16_ext(const uint16_t* A, int lda, const uint16_t* A2, int lda2, int K1,
+                                    const uint16_t* W, int ldw, int M, int N, int K, int epi_flags,
+                                    const float* bias, const float* resid_in, int ld_resid,
+                                    float* out_f32, int ld_f32, uint16_t* out_bf16, int ld_bf16,
+                                    const uspace_gemm_ext* ext, uspace_stream_t stream) {
     if (!A || !W || M <= 0 || N <= 0 || K <= 0) return USPACE_ERR_ARG;
     if (K % BK || K1 % BK || K1 <= 0 || K1 > K || (N & 3)) return USPACE_ERR_ARG;
     if (K1 < K && !A2) return USPACE_ERR_ARG;
@@ -571,7 +703,31 @@ extern "C" int uspace_gemm_bf16(const uint16_t* A, int lda, const uint16_t* A2, 
         if (K != 2 * K1 || (K1 & (K1 - 1))) return USPACE_ERR_ARG;   // two equal power-of-two slabs
         while ((1 << g.k1_log2) < K1) ++g.k1_log2;
     }
+    g.row_c = nullptr; g.out_cen = nullptr; g.part_out = nullptr; g.part_in = nullptr; g.colsum = nullptr; g.c_out = nullptr;
+    g.ld_cen = 0; g.np_in = 0; g.inv_d = 0.f; g.eps = 0.f;
+    if (ext) {
+        g.row_c = ext->row_c; g.out_cen = ext->out_cen; g.ld_cen = ext->ld_cen; g.part_out = ext->part_out;
+        g.part_in = ext->part_in; g.np_in = ext->np_in; g.colsum = ext->colsum; g.c_out = ext->c_out;
+        g.inv_d = ext->norm_dim > 0 ? 1.0f / (float)ext->norm_dim : 0.f;
+        g.eps = ext->eps;
+    }
+    if (epi_flags & USPACE_EPI_CEN_OUT) {
+        if (!g.row_c || !g.out_cen || !g.part_out || (g.ld_cen & 3)) return USPACE_ERR_ARG;
+    }
+    if (epi_flags & USPACE_EPI_LN_IN) {
+        if (!g.part_in || g.np_in <= 0 || !g.colsum || g.inv_d <= 0.f || (g.c_out && !g.row_c)) return USPACE_ERR_ARG;
+    }
     return dispatch_flags(g, epi_flags, (hipStream_t)stream);
+}
+
+extern "C" int uspace_gemm_bf16(const uint16_t* A, int lda, const uint16_t* A2, int lda2, int K1,
+                                const uint16_t* W, int ldw, int M, int N, int K, int epi_flags,
+                                const float* bias, const float* resid_in, int ld_resid,
+                                float* out_f32, int ld_f32, uint16_t* out_bf16, int ld_bf16,
+                                uspace_stream_t stream) {
+    if (epi_flags & (USPACE_EPI_CEN_OUT | USPACE_EPI_LN_IN)) return USPACE_ERR_ARG;
+    return uspace_gemm_bf16_ext(A, lda, A2, lda2, K1, W, ldw, M, N, K, epi_flags, bias, resid_in, ld_resid, out_f32, ld_f32,
+                                out_bf16, ld_bf16, nullptr, stream);
 }
 
 // acc[m, n] = sum_t A[m + row_shift[t], 0:K1] . W[n, t*K1:(t+1)*K1]   -- e.g. a 3x3 convolution over a
@@ -599,6 +755,9 @@ extern "C" int uspace_gemm_slabs_bf16(const uint16_t* A, int lda, const uint16_t
     g.k1_log2 = 0;
     while ((1 << g.k1_log2) < K1) ++g.k1_log2;
     for (int i = 0; i < 9; ++i) g.slab_shift[i] = i < n_slab ? row_shift[i] : 0;
+    g.row_c = nullptr; g.out_cen = nullptr; g.part_out = nullptr; g.part_in = nullptr; g.colsum = nullptr; g.c_out = nullptr;
+    g.ld_cen = 0; g.np_in = 0; g.inv_d = 0.f; g.eps = 0.f;
+    if (epi_flags & (USPACE_EPI_CEN_OUT | USPACE_EPI_LN_IN)) return USPACE_ERR_ARG;
     return dispatch_flags(g, epi_flags, (hipStream_t)stream);
 }
 
