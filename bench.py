@@ -188,7 +188,8 @@ def main():
             solve(args.solver)
         # roofline of the dominant kernel: fc1 GEMM (+bias +GELU -> bf16), timed by HIP events on its own stream
         D, Hd = cfg["embed_dim"], 4 * cfg["embed_dim"]
-        fc1_flags = _hip.EPI_BIAS | _hip.EPI_GELU | _hip.EPI_OUT_BF16
+        fold = os.environ.get("USPACE_LN_FOLD", "1") != "0"     # norm2 folded into fc1 (default) or a separate launch
+        fc1_flags = _hip.EPI_BIAS | _hip.EPI_GELU | _hip.EPI_OUT_BF16 | (_hip.EPI_LN_IN if fold else 0)
         if rank == 0:
             _hip.prof_gemm_begin(fc1_flags, Hd, D, 8192)
         fence()
@@ -263,7 +264,7 @@ def main():
             tp = os.path.join(ROOT, "profiles", "fc1_traffic.json")
             if os.path.exists(tp):
                 traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
-            line["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<256,256,2,4,BIAS|GELU|OUT_BF16> (fc1)",
+            line["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<256,256,2,4," + ("LN_IN|" if fold else "") + "BIAS|GELU|OUT_BF16> (fc1)",
                                 "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
                                 "launches": fc1_n, "avg_us": 1e6 * avg_s, "flops_per_launch": flops}

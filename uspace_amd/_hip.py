@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libuspace_hip.so")
 
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_OUT_BF16 = 1, 2, 4, 8, 16
+EPI_CEN_OUT, EPI_LN_IN = 32, 64          # uspace_gemm_bf16_ext only (LayerNorm folded through the GEMMs)
 
 _ERR = {-1: "USPACE_ERR_ARG", -2: "USPACE_ERR_LAUNCH", -3: "USPACE_ERR_WORKSPACE"}
 
@@ -59,6 +60,9 @@ SIGNATURES = {
     "uspace_gemm_bf16_ext": (_I, [_P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I,
                                   ctypes.POINTER(GemmExt), _P]),
     "uspace_gemm_part_slots": (_I, [_I, _I]),
+    "uspace_fold_layernorm": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "uspace_center_rows": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "uspace_uvit_set_ln_fold": (_I, [_I]),
     "uspace_gemm_tile_choice": (_I, [_I, _I, ctypes.POINTER(_I)]),
     "uspace_gemm_slabs_bf16": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, ctypes.POINTER(_I), _I, _P, _P, _I, _P, _I, _P, _I, _P]),
     "uspace_layernorm_f32_bf16": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),

@@ -102,7 +102,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     static_assert(BM % ROWS_PER_ISSUE == 0 && BN % ROWS_PER_ISSUE == 0, "tile/threads mismatch");
     static_assert(TM % 2 == 0 && TN % WM == 0 && (WM == 2 || WM == 4), "wave tile shape");
 
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+    // LayerNorm folding: per-row values of this tile (main rows, then the 16 strip rows) are fetched at kernel start
+    // (their latency sits under the first tile) and parked behind the stage buffers: consumer (d, rstd), producer
+    // (row_c, -).  They are written and read with inline-asm DS instructions: a second compiler-visible LDS object /
+    // LDS store makes the backend guard every fragment read of the K loop with s_waitcnt vmcnt(0) against the
+    // in-flight LDS-DMA (measured: fc1 +28 us), which undoes the load / compute overlap the loop is built on.
+    constexpr bool ROWV = (FLAGS & (USPACE_EPI_LN_IN | USPACE_EPI_CEN_OUT)) != 0;
+    constexpr int ROWV_BYTES = ROWV ? (BM + 16) * 8 : 0;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES + ROWV_BYTES];
+    const uint32_t rowv_lds = (uint32_t)(uintptr_t)(US_LDS char*)(smem + 2 * STAGE_BYTES);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -282,7 +290,54 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     stage_a(0, 0);
     stage_w(0, 0);
     if (nk > 1) stage_a(1, 1);
+    // LayerNorm folding: thread t fetches the per-row values of tile row t (main rows, then the 16 strip rows) right
+    // behind the first LDS-DMA stages -- their latency overlaps the first tile's -- and parks them in LDS after the barrier
+    float2 pr[ROWV ? 8 : 1];
+    float rc_v = 0.f;
+    int rv_m = -1;
+    if constexpr (ROWV) {
+        static_assert(BM + 16 <= THREADS || !ROWV, "one thread per tile row");
+        const int t = tid;
+        if (t < BM + (XTRA ? 16 : 0)) {
+            const bool strip = t >= BM;
+            const int m = strip ? x0 + (t - BM) : m0 + t;
+            const bool ok = strip ? ((t - BM) < g.xrows && m < g.M) : (m < m_lim);
+            if (ok) {
+                rv_m = m;
+                if constexpr ((FLAGS & USPACE_EPI_LN_IN) != 0) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        pr[q] = q < g.np_in ? *(const float2*)(g.part_in + ((size_t)m * g.np_in + q) * 2) : make_float2(0.f, 0.f);
+                    if (n0 == 0 && g.c_out) rc_v = g.row_c[m];
+                } else {
+                    rc_v = g.row_c[m];
+                }
+            }
+        }
+    }
     __syncthreads();
+    if constexpr (ROWV) {
+        if (tid < BM + 16) {
+            float2 v = make_float2(0.f, 1.f);
+            if (rv_m >= 0) {
+                if constexpr ((FLAGS & USPACE_EPI_LN_IN) != 0) {
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        s1 += pr[q].x;
+                        s2 += pr[q].y;
+                    }
+                    const float d = s1 * g.inv_d;
+                    v = make_float2(d, rsqrtf(fmaxf(s2 * g.inv_d - d * d, 0.f) + g.eps));
+                    if (n0 == 0 && g.c_out) g.c_out[rv_m] = rc_v + d;     // N tile 0 publishes the row mean
+                } else {
+                    v = make_float2(rc_v, 0.f);
+                }
+            }
+            // read in the epilogue, many barriers later
+            asm volatile("ds_write_b64 %0, %1" ::"v"(rowv_lds + (uint32_t)tid * 8u), "v"(v) : "memory");
+        }
+    }
     LOAD_A(af0, smem, 0, c_k0)
     LOAD_W(wf0, smem, c_k0)
     if constexpr (XTRA) { LOAD_X(xf0, smem, c_k0) }
@@ -361,17 +416,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
             cs4[j] = *(const f32x4*)(g.colsum + n);
         }
     }
-    // consumer: this row's (d, rstd) from the producer's per-N-tile partial sums
-    auto row_stats = [&](int m, float& d, float& rstd) {
-        float s1 = 0.f, s2 = 0.f;
-        for (int q = 0; q < g.np_in; ++q) {
-            const float2 pq = *(const float2*)(g.part_in + ((size_t)m * g.np_in + q) * 2);
-            s1 += pq.x;
-            s2 += pq.y;
-        }
-        d = s1 * g.inv_d;
-        rstd = rsqrtf(fmaxf(s2 * g.inv_d - d * d, 0.f) + g.eps);
-    };
     float ps1 = 0.f, ps2 = 0.f;   // producer: running partial sums of the row being emitted
     float row_d = 0.f, row_r = 1.f, row_cv = 0.f;
     auto emit = [&](f32x4 v, const f32x4& b, int m, int n, const f32x4& cs) {
@@ -403,19 +447,33 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     float* const red = (float*)smem;             // CEN: [BM + 16 rows][WM * WN slots][2] partials (LDS is free after the K loop)
     constexpr int RSLOTS = WM * WN;
     if constexpr (CEN) __syncthreads();          // every wave has finished reading the last K tile
-    auto row_begin = [&](int m, bool valid) {
+    // this lane's per-row values: TM main rows (sub-tile i -> row wm*(BM/WM) + i*16 + fr) and the strip row BM + fr
+    float2 rv[ROWV ? TM + 1 : 1];
+    if constexpr (ROWV) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            asm volatile("ds_read_b64 %0, %1" : "=v"(rv[i]) : "v"(rowv_lds + (uint32_t)(wm * (BM / WM) + i * 16 + fr) * 8u) : "memory");
+        asm volatile("ds_read_b64 %0, %1" : "=v"(rv[TM]) : "v"(rowv_lds + (uint32_t)(BM + fr) * 8u) : "memory");
+        // one wait for all of them; the operands are tied so nothing is consumed (or moved) before it
+        if constexpr (TM == 8)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4]), "+v"(rv[5]), "+v"(rv[6]), "+v"(rv[7]), "+v"(rv[8]));
+        else if constexpr (TM == 6)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4]), "+v"(rv[5]), "+v"(rv[6]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4]));
+        static_assert(!ROWV || TM == 8 || TM == 6 || TM == 4, "row-value fetch is written for TM = 8 / 6 / 4");
+    }
+    auto row_begin = [&](int ri) {            // ri: index into rv (sub-tile i, or TM for the strip row)
         if constexpr (LN_IN) {
-            if (valid) row_stats(m, row_d, row_r);
+            row_d = rv[ri].x;
+            row_r = rv[ri].y;
         }
         if constexpr (CEN) {
-            row_cv = valid ? g.row_c[m] : 0.f;
+            row_cv = rv[ri].x;
             ps1 = ps2 = 0.f;
         }
     };
     auto row_end = [&](int m, bool valid, int lrow, int slot) {
-        if constexpr (LN_IN) {
-            if (valid && n0 == 0 && wn == 0 && fq == 0 && g.c_out && slot >= 0) g.c_out[m] = g.row_c[m] + row_d;
-        }
         if constexpr (CEN) {
             float a = ps1, bq = ps2;
             a += __shfl_xor(a, 16, 64);
@@ -433,7 +491,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + wm * (BM / WM) + i * 16 + fr;
-            row_begin(m, true);
+            row_begin(i);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 emit(acc[i][j], bias4[j], m, n0 + wn * (BN / WN) + j * 16 + fq * 4, cs4[LN_IN ? j : 0]);
@@ -444,7 +502,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + wm * (BM / WM) + i * 16 + fr;
             const bool vrow = m < m_lim;
-            row_begin(vrow ? m : 0, vrow);
+            row_begin(i);
             if (vrow) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
@@ -459,7 +517,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     if constexpr (XTRA) {
         const int m = x0 + fr;
         const bool vrow = fr < g.xrows && m < g.M;
-        row_begin(vrow ? m : 0, vrow);
+        row_begin(TM);
         if (vrow) {
 #pragma unroll
             for (int j = 0; j < XN; ++j) {
@@ -715,7 +773,7 @@ extern "C" int uspace_gemm_bf16_ext(const uint16_t* A, int lda, const uint16_t* 
         if (!g.row_c || !g.out_cen || !g.part_out || (g.ld_cen & 3)) return USPACE_ERR_ARG;
     }
     if (epi_flags & USPACE_EPI_LN_IN) {
-        if (!g.part_in || g.np_in <= 0 || !g.colsum || g.inv_d <= 0.f || (g.c_out && !g.row_c)) return USPACE_ERR_ARG;
+        if (!g.part_in || g.np_in <= 0 || g.np_in > 8 || !g.colsum || g.inv_d <= 0.f || (g.c_out && !g.row_c)) return USPACE_ERR_ARG;
     }
     return dispatch_flags(g, epi_flags, (hipStream_t)stream);
 }

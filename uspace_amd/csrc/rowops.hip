@@ -62,6 +62,76 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// LayerNorm folding, pack time: Wf[n, k] = bf16(W[n, k] * gamma[k]), colsum[n] = sum_k Wf[n, k] (of the ROUNDED values: the
+// consumer's algebra uses exactly what the MFMA multiplies), bias_out[n] = bias[n] + sum_k W[n, k] * beta[k].  One block per n.
+__global__ __launch_bounds__(256) void fold_ln_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ bias,
+                                                      bf16_t* __restrict__ Wf, float* __restrict__ bias_out,
+                                                      float* __restrict__ colsum, int K) {
+    __shared__ float red[2][4];
+    const int n = blockIdx.x;
+    float cs = 0.f, bf = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float w = W[(size_t)n * K + k];
+        const bf16_t h = f2bf(w * gamma[k]);
+        Wf[(size_t)n * K + k] = h;
+        cs += bf2f(h);
+        bf += w * beta[k];
+    }
+    cs = wave_sum(cs);
+    bf = wave_sum(bf);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = cs;
+        red[1][threadIdx.x >> 6] = bf;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        colsum[n] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        bias_out[n] = (bias ? bias[n] : 0.f) + ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+    }
+}
+
+// LayerNorm folding, first norm of a forward: rows centred by their own mean.  xc = bf16(x - mean), c = mean,
+// part[m] = (sum(x - mean), sum((x - mean)^2)) as a single partial-sum slot.  One wave per row (as layernorm_kernel).
+template <int NV>
+__global__ __launch_bounds__(256) void center_stats_kernel(const float* __restrict__ x, bf16_t* __restrict__ xc,
+                                                           float* __restrict__ c, float* __restrict__ part, int M, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * D;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int cc = (i * 64 + lane) * 4;
+        v[i] = cc < D ? *(const f32x4*)(xr + cc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int cc = (i * 64 + lane) * 4;
+        if (cc < D) {
+            const f32x4 a = v[i] - mean;
+            s1 += (a[0] + a[1]) + (a[2] + a[3]);
+            s2 += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]);
+            uint2 pk;
+            pk.x = pack_bf2(a[0], a[1]);
+            pk.y = pack_bf2(a[2], a[3]);
+            *(uint2*)(xc + (size_t)row * D + cc) = pk;
+        }
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+        c[row] = mean;
+        part[2 * (size_t)row] = s1;
+        part[2 * (size_t)row + 1] = s2;
+    }
+}
+
 // CLIP text embeddings (HF CLIPTextEmbeddings: token_embedding[ids] + position_embedding[0..L-1]); one block per token.
 __global__ __launch_bounds__(256) void table_embed_kernel(const int* __restrict__ ids, const float* __restrict__ tok_table,
                                                           const float* __restrict__ pos_table, float* __restrict__ out,
@@ -617,6 +687,27 @@ extern "C" int uspace_layernorm_f32(const float* x, const float* gamma, const fl
     else if (D <= 1024) hipLaunchKernelGGL((layernorm_kernel<4, true>), dim3(grid), dim3(256), 0, s, x, gamma, beta, yy, M, D, eps);
     else if (D <= 2048) hipLaunchKernelGGL((layernorm_kernel<8, true>), dim3(grid), dim3(256), 0, s, x, gamma, beta, yy, M, D, eps);
     else hipLaunchKernelGGL((layernorm_kernel<16, true>), dim3(grid), dim3(256), 0, s, x, gamma, beta, yy, M, D, eps);
+    US_CHECK_LAUNCH();
+    return USPACE_OK;
+}
+
+extern "C" int uspace_fold_layernorm(const float* W, const float* gamma, const float* beta, const float* bias, uint16_t* Wf,
+                                     float* bias_out, float* colsum, int N, int K, uspace_stream_t stream) {
+    if (!W || !gamma || !beta || !Wf || !bias_out || !colsum || N <= 0 || K <= 0) return USPACE_ERR_ARG;
+    hipLaunchKernelGGL(fold_ln_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, W, gamma, beta, bias, Wf, bias_out, colsum, K);
+    US_CHECK_LAUNCH();
+    return USPACE_OK;
+}
+
+extern "C" int uspace_center_rows(const float* x, uint16_t* xc, float* c, float* part, int M, int D, uspace_stream_t stream) {
+    if (!x || !xc || !c || !part || M <= 0 || D <= 0 || (D & 3) || D > 4096) return USPACE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = us_cdiv(M, 4);
+    if (D <= 256) hipLaunchKernelGGL(center_stats_kernel<1>, dim3(grid), dim3(256), 0, s, x, xc, c, part, M, D);
+    else if (D <= 512) hipLaunchKernelGGL(center_stats_kernel<2>, dim3(grid), dim3(256), 0, s, x, xc, c, part, M, D);
+    else if (D <= 1024) hipLaunchKernelGGL(center_stats_kernel<4>, dim3(grid), dim3(256), 0, s, x, xc, c, part, M, D);
+    else if (D <= 2048) hipLaunchKernelGGL(center_stats_kernel<8>, dim3(grid), dim3(256), 0, s, x, xc, c, part, M, D);
+    else hipLaunchKernelGGL(center_stats_kernel<16>, dim3(grid), dim3(256), 0, s, x, xc, c, part, M, D);
     US_CHECK_LAUNCH();
     return USPACE_OK;
 }

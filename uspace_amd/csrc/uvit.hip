@@ -3,6 +3,7 @@
 // as a fixed sequence of gfx950 kernels on the caller's stream.  No allocation, no sync:
 // the caller provides the packed-weights blob and a workspace sized by
 // uspace_uvit_workspace_bytes(); the sequence is hipGraph-capturable.
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -34,6 +35,9 @@ struct Layout {
 struct BlockIdx {
     int skip_w = -1, skip_b = -1;
     int n1w, n1b, qkv, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b;
+    // derived at pack time for the LayerNorm-folded path (not parameters): gamma-folded weights, beta-folded biases,
+    // column sums of the folded bf16 weights
+    int qkv_f, qkv_fb, qkv_cs, fc1_f, fc1_fb, fc1_cs;
 };
 
 struct Model {
@@ -42,6 +46,7 @@ struct Model {
     std::vector<BlockIdx> blk;
     int ng, nb, dw, db, convw, convb;
     int L, extras, npatch, nblocks;
+    int n_params;   // entries of lay.p that are parameters; the rest are derived tensors
 };
 
 bool valid_cfg(const uspace_uvit_config* c) {
@@ -99,11 +104,20 @@ Model build_model(const uspace_uvit_config& c) {
     m.db = m.lay.add(PD, F32);
     m.convw = m.lay.add((long)c.in_chans * c.in_chans * 9, F32);
     m.convb = m.lay.add(c.in_chans, F32);
+    m.n_params = (int)m.lay.p.size();
+    for (BlockIdx& b : m.blk) {
+        b.qkv_f = m.lay.add(3 * D * D, BF16);
+        b.qkv_fb = m.lay.add(3 * D, F32);
+        b.qkv_cs = m.lay.add(3 * D, F32);
+        b.fc1_f = m.lay.add(Hd * D, BF16);
+        b.fc1_fb = m.lay.add(Hd, F32);
+        b.fc1_cs = m.lay.add(Hd, F32);
+    }
     return m;
 }
 
 struct Workspace {
-    size_t x, xb, h, qkv, f, skips, ctx_bf, ctx_f32, head, total;
+    size_t x, xb, h, qkv, f, skips, ctx_bf, ctx_f32, head, xc, part, cbuf, total;
 };
 
 Workspace plan_workspace(const uspace_uvit_config& c, const Model& m, int B) {
@@ -120,27 +134,24 @@ Workspace plan_workspace(const uspace_uvit_config& c, const Model& m, int B) {
     w.ctx_bf = take(c.clip_dim > 0 ? (size_t)B * c.n_extra * c.clip_dim * 2 : 0);
     w.ctx_f32 = take(c.clip_dim > 0 ? (size_t)B * c.n_extra * D * 4 : 0);
     w.head = take((size_t)B * c.in_chans * c.img_size * c.img_size * 4);
+    w.xc = take(M * D * 2);                          // LayerNorm folding: centred bf16 copy of the residual stream
+    w.part = take(M * (size_t)us_cdiv((int)D, 128) * 2 * 4);   // per-row partial sums, one slot per producer N tile
+    w.cbuf = take(M * 4);                            // per-row centring constants (row means at the last norm)
     w.total = off;
     return w;
 }
-
-#define US_TRY(expr)                  \
-    do {                              \
-        int rc__ = (expr);            \
-        if (rc__ != USPACE_OK) return rc__; \
-    } while (0)
 
 }  // namespace
 
 extern "C" int uspace_uvit_num_params(const uspace_uvit_config* cfg) {
     if (!valid_cfg(cfg)) return USPACE_ERR_ARG;
-    return (int)build_model(*cfg).lay.p.size();
+    return build_model(*cfg).n_params;
 }
 
 extern "C" long uspace_uvit_param_numel(const uspace_uvit_config* cfg, int index) {
     if (!valid_cfg(cfg)) return USPACE_ERR_ARG;
     const Model m = build_model(*cfg);
-    if (index < 0 || index >= (int)m.lay.p.size()) return USPACE_ERR_ARG;
+    if (index < 0 || index >= m.n_params) return USPACE_ERR_ARG;
     return m.lay.p[index].numel;
 }
 
@@ -159,7 +170,7 @@ extern "C" int uspace_uvit_pack_weights(const uspace_uvit_config* cfg, const flo
                                         void* blob, size_t blob_bytes, uspace_stream_t stream) {
     if (!valid_cfg(cfg) || !params || !blob) return USPACE_ERR_ARG;
     const Model m = build_model(*cfg);
-    if (n_params != (int)m.lay.p.size()) return USPACE_ERR_ARG;
+    if (n_params != m.n_params) return USPACE_ERR_ARG;
     if (blob_bytes < m.lay.bytes) return USPACE_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     for (int i = 0; i < n_params; ++i) {
@@ -173,6 +184,30 @@ extern "C" int uspace_uvit_pack_weights(const uspace_uvit_config* cfg, const flo
                 return USPACE_ERR_LAUNCH;
         }
     }
+    // LayerNorm folding: W' = bf16(W * gamma), bias' = bias + W beta, column sums of W' (qkv has no bias of its own)
+    const int D = cfg->embed_dim, Hd = cfg->mlp_hidden;
+    auto at = [&](int idx) { return (char*)blob + m.lay.p[idx].offset; };
+    for (const BlockIdx& b : m.blk) {
+        US_TRY(uspace_fold_layernorm(params[b.qkv], params[b.n1w], params[b.n1b], nullptr, (uint16_t*)at(b.qkv_f),
+                                     (float*)at(b.qkv_fb), (float*)at(b.qkv_cs), 3 * D, D, stream));
+        US_TRY(uspace_fold_layernorm(params[b.fc1w], params[b.n2w], params[b.n2b], params[b.fc1b], (uint16_t*)at(b.fc1_f),
+                                     (float*)at(b.fc1_fb), (float*)at(b.fc1_cs), Hd, D, stream));
+    }
+    return USPACE_OK;
+}
+
+namespace {
+int g_ln_fold = -1;   // -1: follow USPACE_LN_FOLD (default on)
+bool ln_fold_enabled() {
+    if (g_ln_fold >= 0) return g_ln_fold != 0;
+    const char* e = getenv("USPACE_LN_FOLD");
+    return !(e && e[0] == '0');
+}
+}  // namespace
+
+extern "C" int uspace_uvit_set_ln_fold(int mode) {
+    if (mode < -1 || mode > 1) return USPACE_ERR_ARG;
+    g_ln_fold = mode;
     return USPACE_OK;
 }
 
@@ -198,6 +233,10 @@ extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* bl
     uint16_t* qkv = (uint16_t*)(ws + w.qkv);
     uint16_t* f = (uint16_t*)(ws + w.f);
     uint16_t* skips = (uint16_t*)(ws + w.skips);
+    uint16_t* xc = (uint16_t*)(ws + w.xc);
+    float* part = (float*)(ws + w.part);
+    float* cbuf = (float*)(ws + w.cbuf);
+    const bool fold = ln_fold_enabled() && uspace_gemm_part_slots(B * m.L, c.embed_dim) <= 8;   // consumers read <= 8 partial slots per row
     const size_t MD = (size_t)M * D;
 
     constexpr int B_ = USPACE_EPI_BIAS, G_ = USPACE_EPI_GELU, R_ = USPACE_EPI_RESIDUAL, F_ = USPACE_EPI_OUT_F32,
@@ -222,6 +261,62 @@ extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* bl
                                PF(m.pos), x, nullptr, B, c.in_chans, c.img_size, c.patch_size, D, stream));
 
     const int half = c.depth / 2;
+    if (fold) {
+        // LayerNorm folded through the GEMMs around it (include/uspace_hip.h, uspace_gemm_ext): every producer of x
+        // (skip_linear, proj, fc2 before a norm) also leaves a centred bf16 copy xc and per-row partial sums; qkv and fc1
+        // read xc with gamma-folded weights and finish the normalisation in their epilogues.  No LayerNorm launch
+        // except the first centring pass; the residual stream x itself is unchanged (fp32).
+        constexpr int C_ = USPACE_EPI_CEN_OUT, L_ = USPACE_EPI_LN_IN;
+        const int slots = uspace_gemm_part_slots(M, D);
+        if (slots <= 0) return USPACE_ERR_ARG;
+        auto PFx = [&](int idx) { return (const float*)(wb + m.lay.p[idx].offset); };
+        US_TRY(uspace_center_rows(x, xc, cbuf, part, M, D, stream));
+        int np = 1;                                   // partial-sum slots of whoever wrote xc last
+        uspace_gemm_ext prod{};                       // producers: centre by cbuf, write xc + part
+        prod.row_c = cbuf; prod.out_cen = xc; prod.ld_cen = D; prod.part_out = part; prod.norm_dim = D; prod.eps = 1e-5f;
+        for (int i = 0; i < m.nblocks; ++i) {
+            const BlockIdx& b = m.blk[i];
+            const bool is_in = i < half, is_out = i > half, is_last = i == m.nblocks - 1;
+            if (is_out) {
+                const uint16_t* skip = skips + (size_t)(m.nblocks - 1 - i) * MD;
+                US_TRY(uspace_gemm_bf16_ext(xb, D, skip, D, D, PH(b.skip_w), 2 * D, M, D, 2 * D, C_ | B_ | F_, PF(b.skip_b),
+                                            nullptr, 0, x, D, nullptr, 0, &prod, stream));
+                np = slots;
+            }
+            uspace_gemm_ext cons{};
+            cons.row_c = cbuf; cons.c_out = cbuf; cons.part_in = part; cons.np_in = np; cons.norm_dim = D; cons.eps = 1e-5f;
+            cons.colsum = PFx(b.qkv_cs);
+            US_TRY(uspace_gemm_bf16_ext(xc, D, nullptr, 0, D, PH(b.qkv_f), D, M, 3 * D, D, L_ | B_ | H_, PFx(b.qkv_fb), nullptr, 0,
+                                        nullptr, 0, qkv, 3 * D, &cons, stream));
+            const float* ks = io->key_scale ? io->key_scale + (size_t)i * B * L : nullptr;
+            US_TRY(uspace_attention_bf16(qkv, ks, h, B, L, H, stream));
+            US_TRY(uspace_gemm_bf16_ext(h, D, nullptr, 0, D, PH(b.projw), D, M, D, D, C_ | B_ | R_ | F_, PF(b.projb), x, D, x, D,
+                                        nullptr, 0, &prod, stream));
+            np = slots;
+            cons.np_in = np;
+            cons.colsum = PFx(b.fc1_cs);
+            US_TRY(uspace_gemm_bf16_ext(xc, D, nullptr, 0, D, PH(b.fc1_f), D, M, Hd, D, L_ | B_ | G_ | H_, PFx(b.fc1_fb), nullptr, 0,
+                                        nullptr, 0, f, Hd, &cons, stream));
+            if (is_in) {
+                // the next block starts with a norm: centred copy + partials, plus the raw bf16 skip
+                US_TRY(uspace_gemm_bf16_ext(f, Hd, nullptr, 0, Hd, PH(b.fc2w), Hd, M, D, Hd, C_ | B_ | R_ | F_ | H_, PF(b.fc2b), x, D,
+                                            x, D, skips + (size_t)i * MD, D, &prod, stream));
+            } else {
+                // mid / out blocks: the next consumer is skip_linear (raw bf16 xb) or the head (its own norm)
+                uint16_t* copy = is_last ? nullptr : xb;
+                US_TRY(uspace_gemm_bf16(f, Hd, nullptr, 0, Hd, PH(b.fc2w), Hd, M, D, Hd, copy ? (B_ | R_ | F_ | H_) : (B_ | R_ | F_),
+                                        PF(b.fc2b), x, D, x, D, copy, D, stream));
+            }
+            if (i == half) {
+                if (io->mid_tap) {
+                    if (hipMemcpyAsync(io->mid_tap, x, MD * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+                        return USPACE_ERR_LAUNCH;
+                }
+                if (io->mid_delta)
+                    US_TRY(uspace_add_broadcast_rows(x, xb, io->mid_delta, io->mid_scale, io->mid_row_scale, B, (long)L * D, stream));
+            }
+        }
+    } else {
     for (int i = 0; i < m.nblocks; ++i) {
         const BlockIdx& b = m.blk[i];
         const bool is_in = i < half, is_out = i > half, is_last = i == m.nblocks - 1;
@@ -255,6 +350,7 @@ extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* bl
             if (io->mid_delta)  // u-space write hook at the mid block (libs/uvit.py:336, libs/dissection.py:157)
                 US_TRY(uspace_add_broadcast_rows(x, xb, io->mid_delta, io->mid_scale, io->mid_row_scale, B, (long)L * D, stream));
         }
+    }
     }
     US_TRY(uspace_output_head(x, L, m.extras, PF(m.ng), PF(m.nb), PF(m.dw), PF(m.db), PF(m.convw), PF(m.convb),
                               (float*)(ws + w.head), io->out, B, c.in_chans, c.img_size, c.patch_size, D, 1e-5f, stream));
