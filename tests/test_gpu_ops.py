@@ -343,6 +343,7 @@ def test_gemm_tile_configurations_at_full_row_counts(hip, M, N, K, expect):
     (16448, 1024, 64, 512),      # consumer on 128x128 tiles
     (64 * 334, 512, 64, 1536),   # U-ViT-S T2I rows: producer on 192x256 tiles
     (515, 256, 128, 256),        # small everything, ragged rows
+    (4100, 64, 64, 256),         # consumer with a single K tile (no barrier inside its K loop)
 ])
 def test_layernorm_folded_through_gemms(hip, M, D, Kp, N2):
     """Producer (x = A W^T + b + R, also centred bf16 copy + per-row partial sums) followed by a consumer computing
@@ -364,7 +365,7 @@ def test_layernorm_folded_through_gemms(hip, M, D, Kp, N2):
     c = R.mean(axis=1).astype(np.float32)
     lib = hip.lib()
     slots = lib.uspace_gemm_part_slots(M, D)
-    assert slots in (D // 256, D // 128)
+    assert slots in (-(-D // 256), -(-D // 128))
     dA, dW, db = to_dev(A, torch.bfloat16), to_dev(W, torch.bfloat16), to_dev(b)
     x = to_dev(R).clone()
     xc = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")

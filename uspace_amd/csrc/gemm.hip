@@ -446,7 +446,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     // per-row hooks around the emits of one accumulator row (row sub-tile i of this wave / the strip row)
     float* const red = (float*)smem;             // CEN: [BM + 16 rows][WM * WN slots][2] partials (LDS is free after the K loop)
     constexpr int RSLOTS = WM * WN;
-    if constexpr (CEN) __syncthreads();          // every wave has finished reading the last K tile
+    // every wave has finished reading the last K tile (the partial-sum buffer reuses the stage memory) and -- also when
+    // the K loop had a single tile and therefore no barrier of its own -- the per-row values parked above are visible
+    if constexpr (ROWV) __syncthreads();
     // this lane's per-row values: TM main rows (sub-tile i -> row wm*(BM/WM) + i*16 + fr) and the strip row BM + fr
     float2 rv[ROWV ? TM + 1 : 1];
     if constexpr (ROWV) {
