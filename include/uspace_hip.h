@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define USPACE_ABI_VERSION 2
+#define USPACE_ABI_VERSION 3
 
 #define USPACE_OK 0
 #define USPACE_ERR_ARG (-1)         /* bad pointer / size / unsupported shape */

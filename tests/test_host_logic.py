@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     from uspace_amd import _hip
     assert set(_hip.SIGNATURES) == declared
-    assert _hip.lib().uspace_abi_version() == 2
+    assert _hip.lib().uspace_abi_version() == 3
 
 
 def test_config_queries_without_gpu():

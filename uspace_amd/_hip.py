@@ -123,7 +123,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
-        if L.uspace_abi_version() != 2:
+        if L.uspace_abi_version() != 3:
             raise UspaceHipError("libuspace_hip.so ABI version mismatch")
         _lib = L
     return _lib
