@@ -40,20 +40,91 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // erf-GELU (nn.GELU default, reference libs/timm.py:97).  erf by Abramowitz-Stegun 7.1.26
 // (|abs error| <= 1.5e-7, far below the bf16 rounding of the stored result): one v_rcp, one v_exp and
-// six FMAs instead of libm's branchy erff (which cost ~16 us per 256x256 tile round in the fc1 epilogue).
-__device__ __forceinline__ float erf_as(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    p *= t;
-    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
-    const float r = fmaf(-p, e, 1.0f);
-    return copysignf(r, x);
+// a handful of FMAs instead of libm's branchy erff (which cost ~16 us per 256x256 tile round in the fc1 epilogue).
+// With x = |v| / sqrt(2), t = 1 / (1 + p x), P(t) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))):
+//   gelu(v) = v/2 (1 + sign(v) erf(x)) = max(v, 0) - |v| (P(t) / 2) exp(-v^2 / 2)
+// (0.5 v + 0.5 |v| = max(v, 0); the 1/2 is folded into the coefficients, 1/sqrt(2) into p and the exponent).
+#define US_GELU_P 0.23164189f            /* 0.3275911 / sqrt(2) */
+#define US_GELU_A1 0.127414796f
+#define US_GELU_A2 (-0.142248368f)
+#define US_GELU_A3 0.7107068705f
+#define US_GELU_A4 (-0.7265760135f)
+#define US_GELU_A5 0.5307027145f
+#define US_GELU_E (-0.72134752044f)      /* -log2(e) / 2 */
+__device__ __forceinline__ float gelu_erf(float v) {
+    const float ax = fabsf(v);
+    const float t = __builtin_amdgcn_rcpf(fmaf(US_GELU_P, ax, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(v * v * US_GELU_E);
+    float q = fmaf(US_GELU_A5, t, US_GELU_A4);
+    q = fmaf(q, t, US_GELU_A3);
+    q = fmaf(q, t, US_GELU_A2);
+    q = fmaf(q, t, US_GELU_A1);
+    q *= t;
+    return fmaf(-ax, q * e, fmaxf(v, 0.0f));
 }
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752440f)); }
+// The same over NV x 4 values stage by stage: every stage is NV x 4 independent instructions, so the dependent chain of
+// one value (about a dozen operations of 4-8 cycles latency each) is covered by the others.  The one-value-at-a-time
+// form made the fc1 epilogue latency-bound (ISA: one pair of values after the other).
+// Stage boundary: the empty asm statements pin every value of the finished stage at this point of the IR (the
+// optimiser otherwise sinks a value's whole chain next to its use), the scheduling barrier keeps the machine scheduler
+// from pulling the next stage's instructions up value by value.
+#define US_STAGE_END(arr)                                                          \
+    _Pragma("unroll") for (int j_ = 0; j_ < NV; ++j_) asm volatile("" : "+v"(arr[j_])); \
+    __builtin_amdgcn_sched_barrier(0);
+template <int NV>
+__device__ __forceinline__ void gelu_erf_batch(f32x4 (&v)[NV]) {
+    f32x4 t[NV], e[NV], q[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            t[j][c] = fmaf(US_GELU_P, fabsf(v[j][c]), 1.0f);
+            e[j][c] = v[j][c] * v[j][c] * US_GELU_E;
+        }
+    US_STAGE_END(t)
+    US_STAGE_END(e)
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t[j][c] = __builtin_amdgcn_rcpf(t[j][c]);
+    US_STAGE_END(t)
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) e[j][c] = __builtin_amdgcn_exp2f(e[j][c]);
+    US_STAGE_END(e)
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q[j][c] = fmaf(US_GELU_A5, t[j][c], US_GELU_A4);
+    US_STAGE_END(q)
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q[j][c] = fmaf(q[j][c], t[j][c], US_GELU_A3);
+    US_STAGE_END(q)
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q[j][c] = fmaf(q[j][c], t[j][c], US_GELU_A2);
+    US_STAGE_END(q)
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q[j][c] = fmaf(q[j][c], t[j][c], US_GELU_A1);
+    US_STAGE_END(q)
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q[j][c] = q[j][c] * t[j][c] * e[j][c];
+    US_STAGE_END(q)
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[j][c] = fmaf(-fabsf(v[j][c]), q[j][c], fmaxf(v[j][c], 0.0f));
+    US_STAGE_END(v)
+}
+#undef US_STAGE_END
 
 #define US_CHECK_LAUNCH()                                   \
     do {                                                    \

@@ -48,6 +48,7 @@ struct GemmArgs {
     float* c_out;
     int ld_cen, np_in;
     float inv_d, eps;
+    int wide;   // bf16 outputs (out_bf16, out_cen) allow 16-byte stores: row strides % 8 == 0, bases 16-byte aligned
 };
 
 constexpr int BK = 64;           // bf16 elements per K step (128 B per LDS row)
@@ -69,6 +70,17 @@ __device__ __forceinline__ f32x4 pick_b(const f32x4 (&b)[TN], int wm, int j) {
 #pragma unroll
     for (int w = 1; w < WM; ++w) r = (wm == w) ? b[w * XN + j] : r;
     return r;
+}
+
+// Two packed-bf16 column groups of one row (this lane's 4 columns of sub-tiles j and j+1) -> one 16-byte vector.
+// v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of the second, so the
+// lanes of row fq end up with 8 consecutive columns of sub-tile j + (fq & 1) starting at column 8 * (fq >> 1): a wave
+// stores 16 rows x 64 contiguous bytes per instruction instead of 16 x 32 (the epilogue is bound by the number of store
+// instructions: qkv 115 -> 87 us without its stores, `profiles/r02_gemm_ablation.md`).
+__device__ __forceinline__ uint4 widen_pair(uint2 a, uint2 b) {
+    const auto rx = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
+    const auto ry = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
+    return make_uint4(rx[0], ry[0], rx[1], ry[1]);
 }
 
 // byte offset inside a [rows][64] bf16 LDS tile of 16-B chunk `c` of row `r` (swizzled)
@@ -418,12 +430,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     }
     float ps1 = 0.f, ps2 = 0.f;   // producer: running partial sums of the row being emitted
     float row_d = 0.f, row_r = 1.f, row_cv = 0.f;
-    auto emit = [&](f32x4 v, const f32x4& b, int m, int n, const f32x4& cs) {
+    // one accumulator vector = 4 consecutive columns of one row: value (LayerNorm finish, bias), activation, outputs
+    auto emit_pre = [&](f32x4 v, const f32x4& b, const f32x4& cs) -> f32x4 {
         if constexpr (LN_IN) v = (v - row_d * cs) * row_r;
         if constexpr (FLAGS & USPACE_EPI_BIAS) v += b;
-        if constexpr (FLAGS & USPACE_EPI_GELU) {
-            v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
-        }
+        return v;
+    };
+    auto emit_post = [&](const f32x4& v, int m, int n) {
+#ifdef USPACE_ABLATE_NOSTORE
+        asm volatile("" ::"v"(v));
+        return;
+#endif
         if constexpr (FLAGS & USPACE_EPI_OUT_F32) {
             *(f32x4*)(g.out_f32 + (size_t)m * g.ld_f32 + n) = v;
         }
@@ -442,6 +459,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
             p.y = pack_bf2(vc[2], vc[3]);
             *(uint2*)(g.out_cen + (size_t)m * g.ld_cen + n) = p;
         }
+    };
+    auto emit = [&](f32x4 v, const f32x4& b, int m, int n, const f32x4& cs) {
+        f32x4 w[1] = {emit_pre(v, b, cs)};
+        if constexpr (FLAGS & USPACE_EPI_GELU) gelu_erf_batch<1>(w);
+        emit_post(w[0], m, n);
     };
     // per-row hooks around the emits of one accumulator row (row sub-tile i of this wave / the strip row)
     float* const red = (float*)smem;             // CEN: [BM + 16 rows][WM * WN slots][2] partials (LDS is free after the K loop)
@@ -489,14 +511,53 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
         }
     };
     const bool interior = (m0 + BM <= m_lim) && (n0 + BN <= g.N);   // workgroup-uniform
-    if (interior) {
+#ifdef USPACE_ABLATE_NOEPI
+    {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (sacc == 1.2345e30f) g.out_bf16[tid] = 1;
+        return;
+    }
+#endif
+    if (interior && g.wide) {
+        const int nw = n0 + wn * (BN / WN) + (fq & 1) * 16 + (fq >> 1) * 8;   // this lane's column in a widened pair (+ 32 per pair)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + wm * (BM / WM) + i * 16 + fr;
             row_begin(i);
+            // the TN vectors of a row go through the activation together (TN x 4 independent chains)
+            f32x4 v[TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                emit(acc[i][j], bias4[j], m, n0 + wn * (BN / WN) + j * 16 + fq * 4, cs4[LN_IN ? j : 0]);
+            for (int j = 0; j < TN; ++j) v[j] = emit_pre(acc[i][j], bias4[j], cs4[LN_IN ? j : 0]);
+#ifndef USPACE_ABLATE_NOGELU
+            if constexpr (FLAGS & USPACE_EPI_GELU) gelu_erf_batch<TN>(v);
+#endif
+            uint2 pk[TN], pc[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (FLAGS & USPACE_EPI_OUT_F32) *(f32x4*)(g.out_f32 + (size_t)m * g.ld_f32 + n0 + wn * (BN / WN) + j * 16 + fq * 4) = v[j];
+                if constexpr (FLAGS & USPACE_EPI_OUT_BF16) {
+                    pk[j].x = pack_bf2(v[j][0], v[j][1]);
+                    pk[j].y = pack_bf2(v[j][2], v[j][3]);
+                }
+                if constexpr (CEN) {
+                    const f32x4 vc = v[j] - row_cv;
+                    ps1 += (vc[0] + vc[1]) + (vc[2] + vc[3]);
+                    ps2 += (vc[0] * vc[0] + vc[1] * vc[1]) + (vc[2] * vc[2] + vc[3] * vc[3]);
+                    pc[j].x = pack_bf2(vc[0], vc[1]);
+                    pc[j].y = pack_bf2(vc[2], vc[3]);
+                }
+            }
+#ifndef USPACE_ABLATE_NOSTORE
+#pragma unroll
+            for (int j = 0; j < TN; j += 2) {
+                if constexpr (FLAGS & USPACE_EPI_OUT_BF16) *(uint4*)(g.out_bf16 + (size_t)m * g.ld_bf16 + nw + j * 16) = widen_pair(pk[j], pk[j + 1]);
+                if constexpr (CEN) *(uint4*)(g.out_cen + (size_t)m * g.ld_cen + nw + j * 16) = widen_pair(pc[j], pc[j + 1]);
+            }
+#endif
             row_end(m, true, wm * (BM / WM) + i * 16 + fr, wn);   // main rows: wave (wm, wn) fills slot wn of its rows
         }
     } else {
@@ -717,6 +778,13 @@ int dispatch_flags(const GemmArgs& g, int epi_flags, hipStream_t s) {
     }
 }
 
+// 16-byte stores of the bf16 outputs need 16-byte aligned rows
+int wide_ok(const GemmArgs& g, int epi_flags) {
+    if ((epi_flags & USPACE_EPI_OUT_BF16) && ((g.ld_bf16 & 7) || ((uintptr_t)g.out_bf16 & 15))) return 0;
+    if ((epi_flags & USPACE_EPI_CEN_OUT) && ((g.ld_cen & 7) || ((uintptr_t)g.out_cen & 15))) return 0;
+    return 1;
+}
+
 }  // namespace
 
 extern "C" int uspace_gemm_part_slots(int M, int N) {
@@ -765,6 +833,7 @@ extern "C" int uspace_gemm_bf16_ext(const uint16_t* A, int lda, const uint16_t* 
     }
     g.row_c = nullptr; g.out_cen = nullptr; g.part_out = nullptr; g.part_in = nullptr; g.colsum = nullptr; g.c_out = nullptr;
     g.ld_cen = 0; g.np_in = 0; g.inv_d = 0.f; g.eps = 0.f;
+    g.wide = 0;
     if (ext) {
         g.row_c = ext->row_c; g.out_cen = ext->out_cen; g.ld_cen = ext->ld_cen; g.part_out = ext->part_out;
         g.part_in = ext->part_in; g.np_in = ext->np_in; g.colsum = ext->colsum; g.c_out = ext->c_out;
@@ -777,6 +846,7 @@ extern "C" int uspace_gemm_bf16_ext(const uint16_t* A, int lda, const uint16_t* 
     if (epi_flags & USPACE_EPI_LN_IN) {
         if (!g.part_in || g.np_in <= 0 || g.np_in > 8 || !g.colsum || g.inv_d <= 0.f || (g.c_out && !g.row_c)) return USPACE_ERR_ARG;
     }
+    g.wide = wide_ok(g, epi_flags);
     return dispatch_flags(g, epi_flags, (hipStream_t)stream);
 }
 
@@ -818,6 +888,7 @@ extern "C" int uspace_gemm_slabs_bf16(const uint16_t* A, int lda, const uint16_t
     g.row_c = nullptr; g.out_cen = nullptr; g.part_out = nullptr; g.part_in = nullptr; g.colsum = nullptr; g.c_out = nullptr;
     g.ld_cen = 0; g.np_in = 0; g.inv_d = 0.f; g.eps = 0.f;
     if (epi_flags & (USPACE_EPI_CEN_OUT | USPACE_EPI_LN_IN)) return USPACE_ERR_ARG;
+    g.wide = wide_ok(g, epi_flags);
     return dispatch_flags(g, epi_flags, (hipStream_t)stream);
 }
 
