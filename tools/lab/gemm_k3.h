@@ -26,8 +26,10 @@ struct Args {
 constexpr int BK = 64, ROW_BYTES = 128;
 constexpr int TILE_A_BYTES = 256 * ROW_BYTES, TILE_W_BYTES = 256 * ROW_BYTES, STAGE_BYTES = TILE_A_BYTES + TILE_W_BYTES;
 
-template <int FLAGS, int E>
+template <int FLAGS, int E, int PRIO = 0>
 __global__ __launch_bounds__(512) void kernel(const Args g) {
+    // PRIO: 0 no priorities, 1 computing set high, 2 epilogue set high
+    constexpr int PC = PRIO == 1 ? 1 : 0, PE = PRIO == 2 ? 1 : 0;
     constexpr int TM = 8, TN = 4, HM = 4;
     constexpr int RPC = TM / E;   // row groups per epilogue chunk
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
@@ -142,6 +144,7 @@ __global__ __launch_bounds__(512) void kernel(const Args g) {
     if (S > 1) stage_a(kplus(1), 1, set);
     __syncthreads();
     if (set == 0) {
+        if constexpr (PRIO != 0) __builtin_amdgcn_s_setprio(PC);
         LOAD_A(af0, smem, 0, c_k0)
         LOAD_W(wf0, smem, c_k0)
     }
@@ -196,6 +199,7 @@ __global__ __launch_bounds__(512) void kernel(const Args g) {
         const char* nxt = smem + ((s + 1) & 1) * STAGE_BYTES;
         raw_barrier();
         if (resume) {
+            if constexpr (PRIO != 0) __builtin_amdgcn_s_setprio(PC);
             LOAD_A(af0, nxt, 0, c_k0)
             LOAD_W(wf0, nxt, c_k0)
         }
@@ -228,29 +232,38 @@ __global__ __launch_bounds__(512) void kernel(const Args g) {
         compute_step(false);
         advance();
         // ---- epilogue of block t in E chunks, one barrier step each
-        const int nb0 = nrun0 + (2 * t + set) * 128 + wn * 64 + fq * 4;
-        f32x4 bias4[TN];
-        if constexpr (FLAGS & USPACE_EPI_BIAS) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bias4[j] = *(const f32x4*)(g.bias + nb0 + j * 16);
-        }
+        if constexpr (PRIO != 0) __builtin_amdgcn_s_setprio(PE);
+        // lane coordinates re-derived behind an opaque barrier: keeps the store address arithmetic of all chunks from being
+        // hoisted above the K loop (long live ranges -> spills)
+        int fr_e = fr, fq_e = fq;
+        asm volatile("" : "+v"(fr_e), "+v"(fq_e));
+        const int nblk = nrun0 + (2 * t + set) * 128 + wn * 64;
+        const int nw = nblk + (fq_e & 1) * 16 + (fq_e >> 1) * 8;     // widened pair column (+32 per pair)
         const bool more_blocks = t + 1 < T;
         const bf16_t* wnext = wblk + (size_t)256 * g.ldw;
 #pragma unroll
         for (int c = 0; c < E; ++c) {
-            uint2 pk[RPC][TN];
+            uint4 pw[RPC][TN / 2];
 #pragma unroll
             for (int r = 0; r < RPC; ++r) {
                 const int i = c * RPC + r;
+                f32x4 v[TN];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    f32x4 v = acc[i][j];
-                    if constexpr (FLAGS & USPACE_EPI_BIAS) v += bias4[j];
-                    if constexpr (FLAGS & USPACE_EPI_GELU) {
-                        v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
-                    }
-                    pk[r][j].x = pack_bf2(v[0], v[1]);
-                    pk[r][j].y = pack_bf2(v[2], v[3]);
+                    v[j] = acc[i][j];
+                    if constexpr (FLAGS & USPACE_EPI_BIAS) v[j] += *(const f32x4*)(g.bias + nblk + fq_e * 4 + j * 16);
+                }
+                if constexpr (FLAGS & USPACE_EPI_GELU) gelu_erf_batch<TN>(v);
+#pragma unroll
+                for (int j = 0; j < TN; j += 2) {
+                    uint2 p0, p1;
+                    p0.x = pack_bf2(v[j][0], v[j][1]);
+                    p0.y = pack_bf2(v[j][2], v[j][3]);
+                    p1.x = pack_bf2(v[j + 1][0], v[j + 1][1]);
+                    p1.y = pack_bf2(v[j + 1][2], v[j + 1][3]);
+                    const auto rx = __builtin_amdgcn_permlane16_swap(p0.x, p1.x, false, false);
+                    const auto ry = __builtin_amdgcn_permlane16_swap(p0.y, p1.y, false, false);
+                    pw[r][j / 2] = make_uint4(rx[0], ry[0], rx[1], ry[1]);
                 }
             }
             const bool last = c == E - 1;
@@ -264,11 +277,12 @@ __global__ __launch_bounds__(512) void kernel(const Args g) {
 #pragma unroll
             for (int r = 0; r < RPC; ++r) {
                 const int i = c * RPC + r;
-                const int m = m0 + wm * 128 + i * 16 + fr;
+                const int m = m0 + wm * 128 + i * 16 + fr_e;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) *(uint2*)(g.out_bf16 + (size_t)m * g.ld_bf16 + nb0 + j * 16) = pk[r][j];
+                for (int j = 0; j < TN / 2; ++j) *(uint4*)(g.out_bf16 + (size_t)m * g.ld_bf16 + nw + j * 32) = pw[r][j];
             }
             if (w_next) {
+                if constexpr (PRIO != 0) __builtin_amdgcn_s_setprio(PC);
                 LOAD_A(af0, nxt, 0, c_k0)
                 LOAD_W(wf0, nxt, c_k0)
             }

@@ -62,7 +62,7 @@ static void launch_k2(const k2::Args& a) {
 }
 
 static unsigned long long* g_trace = nullptr;
-template <int FLAGS, int E>
+template <int FLAGS, int E, int PRIO = 0>
 static void launch_k3(const k2::Args& a, int T) {
     k3::Args g{};
     g.A = a.A; g.W = a.W; g.bias = a.bias; g.out_bf16 = a.out_bf16;
@@ -70,7 +70,7 @@ static void launch_k3(const k2::Args& a, int T) {
     g.T = T;
     g.runs = a.N / (2 * T * 128);
     g.trace = g_trace;
-    hipLaunchKernelGGL((k3::kernel<FLAGS, E>), dim3((a.M / 256) * g.runs), dim3(512), 0, 0, g);
+    hipLaunchKernelGGL((k3::kernel<FLAGS, E, PRIO>), dim3((a.M / 256) * g.runs), dim3(512), 0, 0, g);
 }
 
 int main(int argc, char** argv) {
@@ -183,13 +183,18 @@ int main(int argc, char** argv) {
             printf(" | noMFMA %.1f noEPI %.1f MFMAonly %.1f", t1, t2, t3);
         }
         if (s.flags == (B_ | G_ | H_) || s.flags == H_ || s.flags == (B_ | H_)) {
-            for (int variant = 0; variant < 4; ++variant) {
+            for (int variant = 0; variant < 6; ++variant) {
                 const int E = (variant & 1) ? 4 : 8;
-                const int T = (variant & 2) ? N / 512 : N / 1024;   // runs = 2 or 4
+                const int prio = variant >> 1;
+                const int T = N / 1024;   // 4 runs per row panel
                 auto run3 = [&]() {
-                    if (s.flags == (B_ | G_ | H_)) { if (E == 8) launch_k3<B_ | G_ | H_, 8>(a, T); else launch_k3<B_ | G_ | H_, 4>(a, T); }
-                    else if (s.flags == H_) { if (E == 8) launch_k3<H_, 8>(a, T); else launch_k3<H_, 4>(a, T); }
-                    else { if (E == 8) launch_k3<B_ | H_, 8>(a, T); else launch_k3<B_ | H_, 4>(a, T); }
+#define K3_CASE(FL)                                                                                                    \
+    if (E == 8) { if (prio == 0) launch_k3<FL, 8, 0>(a, T); else if (prio == 1) launch_k3<FL, 8, 1>(a, T); else launch_k3<FL, 8, 2>(a, T); } \
+    else { if (prio == 0) launch_k3<FL, 4, 0>(a, T); else if (prio == 1) launch_k3<FL, 4, 1>(a, T); else launch_k3<FL, 4, 2>(a, T); }
+                    if (s.flags == (B_ | G_ | H_)) { K3_CASE(B_ | G_ | H_) }
+                    else if (s.flags == H_) { K3_CASE(H_) }
+                    else { K3_CASE(B_ | H_) }
+#undef K3_CASE
                 };
                 HCHECK(hipMemset(dO2, 0, (size_t)M * N * 2));
                 run3();
@@ -206,8 +211,8 @@ int main(int argc, char** argv) {
                     if (d > 0.02 * fmax(1.0, fabs(x))) ++nb;
                 }
                 const float t3 = time_us(run3, reps);
-                printf("\n    k3 E=%d T=%d: %7.1f us %6.0f TF  maxdiff %.3g bad %zu", E, T, t3, fl / t3 * 1e-6, md, nb);
-                if (variant < 2 && getenv("LAB_TRACE")) {
+                printf("\n    k3 E=%d prio=%d: %7.1f us %6.0f TF  maxdiff %.3g bad %zu", E, prio, t3, fl / t3 * 1e-6, md, nb);
+                if (getenv("LAB_TRACE")) {
                     unsigned long long* dt;
                     HCHECK(hipMalloc(&dt, 1024 * 8));
                     HCHECK(hipMemset(dt, 0, 1024 * 8));

@@ -34,7 +34,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int n_slab, k1_log2;  // K is n_slab slabs of K1 = 2^k1_log2 (n_slab > 1); slab s reads A rows shifted by slab_shift[s]
     int slab_shift[9];    // (3x3 convolution over a zero-bordered NHWC map: 9 taps); 0 for the long-skip's second slab
-    int m_main, xrows;   // XTRA: rows [m_main, M) are spread over the workgroups, xrows (<=16) each
+    int m_main, n_strip; // XTRA: rows [m_main, M) are handled as n_strip strips of 16 rows, each owned by the workgroups of one tile row
     // LayerNorm folded through the GEMM (DESIGN.md "LayerNorm folding"):
     //   producer (USPACE_EPI_CEN_OUT): also writes out_cen = bf16(v - row_c[m]) and, per row and N tile, the partial
     //                                  sums (sum, sum of squares) of v - row_c[m] to part_out[m][tiles_n][2];
@@ -92,10 +92,13 @@ __device__ __forceinline__ int lds_off(int r, int c) { return r * ROW_BYTES + ((
 // alternate register set and its share of the next tiles' LDS-DMA loads, then its own MFMAs, so
 // matrix-pipe time covers LDS and HBM latency inside one wave.  One barrier per K tile (phase 3).
 //
-// XTRA: besides its BM x BN tile every workgroup owns `xrows` (<= 16) rows of the region
-// [m_main, M) -- one more 16-row MFMA tile shared by the waves -- so a row count like
-// 64*257 = 64*256 + 64 costs 1/16 more matrix work instead of a nearly empty extra round of
-// workgroups (wave quantisation: 65 x 4 = 260 tiles on 256 CUs is 2 rounds, 64 x 4 is 1).
+// XTRA: the rows [m_main, M) that do not fill a tile row are cut into strips of 16 rows; the workgroups of a few tile
+// rows each own one strip besides their BM x BN tile -- one more 16-row MFMA tile shared by the waves -- so a row
+// count like 64*257 = 64*256 + 64 costs four of the 64 tile rows 1/16 more matrix work instead of a nearly empty extra
+// round of workgroups (wave quantisation: 65 x 4 = 260 tiles on 256 CUs is 2 rounds, 64 x 4 is 1).  The strip owners
+// are spread over the XCDs (tile rows 0, 8, 16, ...); the other workgroups skip the strip work (wave-uniform branches
+// at the scheduling barriers of the K loop).  Round 1 gave every workgroup ceil(64/64) = 1 row, i.e. 15/16 of an MFMA
+// tile wasted in each of them: +6 % matrix work everywhere.
 // ------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int FLAGS, bool XTRA>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
@@ -156,7 +159,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
     const int m_lim = XTRA ? g.m_main : g.M;     // rows >= m_lim belong to the extra strips
-    const int x0 = g.m_main + tile_m * g.xrows;  // first extra row of this workgroup
+    // strip index of this tile row: tile rows 0, 8, 16, ... come first so the owners land on different XCDs
+    const int sk = (g.tiles_m & 7) == 0 ? (tile_m & 7) * (g.tiles_m >> 3) + (tile_m >> 3) : tile_m;
+    const int x0 = g.m_main + sk * 16;           // first extra row of this workgroup
+    const int xr = (XTRA && sk < g.n_strip) ? (g.M - x0 < 16 ? g.M - x0 : 16) : 0;   // its extra rows
+    const bool has_x = xr > 0;                   // workgroup-uniform
 
     // ---- per-lane staging sources: 32-bit BYTE offsets from wave-uniform bases (row clamped into
     //      range; invalid rows are never stored).  Both K slabs share the row stride (checked on host).
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     if constexpr (XTRA) {   // 16-row extra tile: staged by the first two waves (8 rows each)
         const int r = tid >> 3;                  // 0..15 for tid < 128
         const int c = schunk ^ ((r >> 1) & 7);
-        int m = x0 + (r < g.xrows ? r : 0);
+        int m = x0 + (r < xr ? r : 0);
         m = m < g.M ? m : g.M - 1;
         x_off = (uint32_t)(m * g.lda + c * 8) * 2u;
     }
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
                                              16, 0, 0);
         }
         if constexpr (XTRA) {
-            if (wave < 2)
+            if (has_x && wave < 2)
                 __builtin_amdgcn_global_load_lds((const US_GLB void*)(abase + x_off),
                                                  (US_LDS void*)(base + TILE_A_BYTES + TILE_W_BYTES + wave_lds_off),
                                                  16, 0, 0);
@@ -260,7 +267,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
             }
         }
         if constexpr (XTRA) {
-            int m = x0 + (fr < g.xrows ? fr : 0);
+            int m = x0 + (fr < xr ? fr : 0);
             m = m < g.M ? m : g.M - 1;
 #pragma unroll
             for (int j = 0; j < XN; ++j) {
@@ -286,14 +293,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
 #define LOAD_W(dst, base, ck)                                                                       \
     _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_)                                               \
         dst[j_] = *(const bf16x8*)((base) + w_lds + j_ * 16 * ROW_BYTES + (ck));
-#define LOAD_X(dst, base, ck) dst = *(const bf16x8*)((base) + x_lds + (ck));
+#define LOAD_X(dst, base, ck) if (has_x) dst = *(const bf16x8*)((base) + x_lds + (ck));
 #define MMA(af, wf, mh, ilo, ihi)                                                                   \
     _Pragma("unroll") for (int i_ = (ilo); i_ < (ihi); ++i_)                                        \
         _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_)                                           \
             acc[(mh) * HM + i_][j_] =                                                               \
                 __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j_], af[i_], acc[(mh) * HM + i_][j_], 0, 0, 0);
 #define MMA_X(xf, wf)                                                                               \
-    if constexpr (XTRA) {                                                                           \
+    if (XTRA && has_x) {                                                                            \
         _Pragma("unroll") for (int j_ = 0; j_ < XN; ++j_)                                           \
             xacc[j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pick_w<WM, XN>(wf, wm, j_), xf, xacc[j_], 0, 0, 0); \
     }
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
         if (t < BM + (XTRA ? 16 : 0)) {
             const bool strip = t >= BM;
             const int m = strip ? x0 + (t - BM) : m0 + t;
-            const bool ok = strip ? ((t - BM) < g.xrows && m < g.M) : (m < m_lim);
+            const bool ok = strip ? ((t - BM) < xr && m < g.M) : (m < m_lim);
             if (ok) {
                 rv_m = m;
                 if constexpr ((FLAGS & USPACE_EPI_LN_IN) != 0) {
@@ -354,16 +361,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     LOAD_W(wf0, smem, c_k0)
     if constexpr (XTRA) { LOAD_X(xf0, smem, c_k0) }
 
+#ifndef USPACE_STAG
+#define USPACE_STAG 0
+#endif
+    // USPACE_STAG (experiment): 1 = the second wave of every SIMD (waves 4-7) issues its LDS-DMA after its remaining
+    // MFMAs instead of before them, so the two waves of a SIMD do not issue DMA at the same moment
+    const bool late = USPACE_STAG != 0 && wave >= (WM * WN) / 2;
 #define KTILE(kt, MORE, MORE2)                                                                     \
     {                                                                                              \
         const char* cur = smem + (kt & 1) * STAGE_BYTES;                                           \
         MMA(af0, wf0, 0, 0, 1)                                                                     \
         MMA_X(xf0, wf0)                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        if (MORE) stage_w(kt + 1, (kt + 1) & 1);                                                   \
+        if (MORE && !late) stage_w(kt + 1, (kt + 1) & 1);                                          \
         LOAD_A(af1, cur, 1, c_k0)                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         MMA(af0, wf0, 0, 1, HM)                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (MORE && late) stage_w(kt + 1, (kt + 1) & 1);                                           \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         MMA(af1, wf0, 1, 0, 1)                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                         \
@@ -384,7 +399,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);                                                         \
         if (MORE) {                                                                                \
             __syncthreads(); /* tile kt+1 landed for everyone; buffer kt&1 is free */              \
-            if (MORE2) stage_a(kt + 2, kt & 1);                                                    \
+            if (MORE2 && !late) stage_a(kt + 2, kt & 1);                                           \
             const char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;                                 \
             LOAD_A(af0, nxt, 0, c_k0)                                                              \
             LOAD_W(wf0, nxt, c_k0)                                                                 \
@@ -392,6 +407,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         MMA(af1, wf1, 1, HM / 2, HM)                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (MORE && MORE2 && late) stage_a(kt + 2, kt & 1);                                        \
         __builtin_amdgcn_sched_barrier(0);                                                         \
     }
     // steady state is branch-free; the last two K tiles are peeled (no further prefetch / barrier)
@@ -579,7 +596,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     }
     if constexpr (XTRA) {
         const int m = x0 + fr;
-        const bool vrow = fr < g.xrows && m < g.M;
+        const bool vrow = fr < xr && m < g.M;
         row_begin(TM);
         if (vrow) {
 #pragma unroll
@@ -602,7 +619,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
         for (int t = tid; t < BM + (XTRA ? 16 : 0); t += THREADS) {
             const bool strip = t >= BM;
             const int m = strip ? x0 + (t - BM) : m0 + t;
-            const bool ok = strip ? ((t - BM) < g.xrows && m < g.M) : (m < m_lim);
+            const bool ok = strip ? ((t - BM) < xr && m < g.M) : (m < m_lim);
             if (!ok) continue;
             float a = 0.f, bq = 0.f;
             const int nslot = strip ? RSLOTS : WN;
@@ -629,11 +646,17 @@ struct Recorder {
 };
 Recorder g_rec;
 
-// Tiling plan: how many BM-row tile rows get their own workgroups, the rest being spread as extra
-// strips.  Cost model: rounds of workgroups over 256 CUs, each round 1/16 longer with strips.
+// Tiling plan: how many BM-row tile rows get their own workgroups, the remaining rows being cut into n_strip strips of 16
+// rows owned by that many tile rows.  Cost model: rounds of workgroups over the CUs; a strip owner does one more 16-row
+// MFMA tile (1/16 of a 256-row tile, 1/8 of a 128-row one), which costs its share of the work plus a tail.
 struct Plan {
-    int tiles_m, m_main, xrows;
+    int tiles_m, m_main, n_strip;
 };
+
+inline double strip_factor(const Plan& p, int BM) {
+    if (p.n_strip <= 0) return 1.0;
+    return 1.0 + ((double)p.n_strip / p.tiles_m) * (16.0 / BM) + 0.01;
+}
 
 inline Plan plan_rows(int M, int BM, int tiles_n, int wg_per_round) {
     const int full = M / BM;
@@ -643,12 +666,12 @@ inline Plan plan_rows(int M, int BM, int tiles_n, int wg_per_round) {
     for (int tm = full; tm >= 1 && tm >= full - 8; --tm) {
         const int rem = M - tm * BM;
         if (rem <= 0) continue;
-        const int xr = us_cdiv(rem, tm);
-        if (xr > 16) break;
-        const double cost = (double)us_cdiv(tm * tiles_n, wg_per_round) * (1.0 + 1.0 / 16.0);
+        if (rem > 16 * tm) break;                     // at most one strip per tile row
+        const Plan p{tm, tm * BM, us_cdiv(rem, 16)};
+        const double cost = (double)us_cdiv(tm * tiles_n, wg_per_round) * strip_factor(p, BM);
         if (cost < best_cost - 1e-9) {
             best_cost = cost;
-            best = Plan{tm, tm * BM, xr};
+            best = p;
         }
     }
     return best;
@@ -661,11 +684,11 @@ int launch(const GemmArgs& a, hipStream_t s, int wg_per_round) {
     const Plan p = plan_rows(g.M, BM, g.tiles_n, wg_per_round);
     g.tiles_m = p.tiles_m;
     g.m_main = p.m_main;
-    g.xrows = p.xrows;
+    g.n_strip = p.n_strip;
     const bool rec = g_rec.on && g_rec.flags == FLAGS && g_rec.N == g.N && g_rec.K == g.K && g_rec.used + 2 <= g_rec.cap;
     if (rec) (void)hipEventRecord(g_rec.ev[g_rec.used], s);
     const dim3 grid(g.tiles_m * g.tiles_n), block(64 * WM * WN);
-    if (p.xrows > 0) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, FLAGS, true>), grid, block, 0, s, g);
+    if (p.n_strip > 0) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, FLAGS, true>), grid, block, 0, s, g);
     else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, FLAGS, false>), grid, block, 0, s, g);
     if (rec) {
         (void)hipEventRecord(g_rec.ev[g_rec.used + 1], s);
@@ -709,7 +732,7 @@ TileChoice choose_tile(int M, int N, int* split_rows) {
     if (a.N <= 128 || a.M < 192) return TILE_SMALL;   // no half-empty 256-wide tiles
     const int tn = us_cdiv(a.N, 256);
     const long big_tiles = (long)(a.M / 256) * tn;
-    auto strip = [](const Plan& p, int bm) { return p.xrows > 0 ? 1.0 + 16.0 / bm : 1.0; };   // one more 16-row MFMA tile per workgroup
+    auto strip = [](const Plan& p, int bm) { return strip_factor(p, bm); };
     const Plan ps = plan_rows(a.M, 128, us_cdiv(a.N, 128), 512);
     const long st = (long)ps.tiles_m * us_cdiv(a.N, 128);
     const double cost_small = ((double)(st / 512) * 0.55 + (st % 512 ? (st % 512 <= 256 ? 0.33 : 0.55) : 0.0)) * strip(ps, 128);
@@ -823,7 +846,7 @@ extern "C" int uspace_gemm_bf16_ext(const uint16_t* A, int lda, const uint16_t* 
     g.M = M; g.N = N; g.K = K; g.K1 = K1;
     g.lda = lda; g.lda2 = lda2; g.ldw = ldw; g.ld_resid = ld_resid; g.ld_f32 = ld_f32; g.ld_bf16 = ld_bf16;
     g.tiles_m = g.tiles_n = 0;
-    g.m_main = M; g.xrows = 0;
+    g.m_main = M; g.n_strip = 0;
     g.n_slab = (K1 < K) ? 2 : 1;
     g.k1_log2 = 0;
     for (int i = 0; i < 9; ++i) g.slab_shift[i] = 0;
@@ -880,7 +903,7 @@ extern "C" int uspace_gemm_slabs_bf16(const uint16_t* A, int lda, const uint16_t
     g.M = M; g.N = N; g.K = K1 * n_slab; g.K1 = K1;
     g.lda = lda; g.lda2 = lda; g.ldw = ldw; g.ld_resid = ld_resid; g.ld_f32 = ld_f32; g.ld_bf16 = ld_bf16;
     g.tiles_m = g.tiles_n = 0;
-    g.m_main = M; g.xrows = 0;
+    g.m_main = M; g.n_strip = 0;
     g.n_slab = n_slab;
     g.k1_log2 = 0;
     while ((1 << g.k1_log2) < K1) ++g.k1_log2;
