@@ -188,7 +188,7 @@ def main():
             solve(args.solver)
         # roofline of the dominant kernel: fc1 GEMM (+bias +GELU -> bf16), timed by HIP events on its own stream
         D, Hd = cfg["embed_dim"], 4 * cfg["embed_dim"]
-        fold = os.environ.get("USPACE_LN_FOLD", "1") != "0"     # norm2 folded into fc1 (default) or a separate launch
+        fold = _hip.lib().uspace_uvit_get_ln_fold() != 0       # norm2 folded into fc1 (default) or a separate launch
         fc1_flags = _hip.EPI_BIAS | _hip.EPI_GELU | _hip.EPI_OUT_BF16 | (_hip.EPI_LN_IN if fold else 0)
         if rank == 0:
             _hip.prof_gemm_begin(fc1_flags, Hd, D, 8192)

@@ -9,7 +9,11 @@
  *   - the caller owns every buffer (weights blob, workspace, inputs, outputs);
  *   - every function enqueues on the caller's hipStream_t and never synchronises;
  *   - return 0 on success, a negative USPACE_ERR_* otherwise; nothing throws;
- *   - no global state (except the optional launch recorder at the end of this header).
+ *   - no per-call global state.  Process-wide state, all of it listed here: (1) the optional launch recorder at the
+ *     end of this header (not thread-safe: one measuring thread); (2) the LayerNorm-fold switch
+ *     uspace_uvit_set_ln_fold / _get_ln_fold (atomic; default on); (3) per kernel, the set of devices on which it has
+ *     been opted in to more than 64 KiB of dynamic LDS (atomic bit mask; any number of GPUs per process); (4) a
+ *     mutex-protected cache of the parameter layout derived from each distinct uspace_uvit_config.
  * bf16 values cross the boundary as raw uint16_t (upper half of an IEEE fp32, RNE).
  */
 #ifndef USPACE_HIP_H
@@ -22,7 +26,7 @@
 extern "C" {
 #endif
 
-#define USPACE_ABI_VERSION 3
+#define USPACE_ABI_VERSION 4
 
 #define USPACE_OK 0
 #define USPACE_ERR_ARG (-1)         /* bad pointer / size / unsupported shape */
@@ -96,8 +100,10 @@ USPACE_API int uspace_fold_layernorm(const float* W, const float* gamma, const f
 /* first norm of a chain: xc = bf16(x - rowmean), c[m] = rowmean, part[m][1][2] = (sum, sum of squares) of x - rowmean */
 USPACE_API int uspace_center_rows(const float* x, uint16_t* xc, float* c, float* part, int M, int D, uspace_stream_t stream);
 /* process-wide switch for the U-ViT forward: 1 = LayerNorm folded through the GEMMs (default), 0 = separate LayerNorm
- * launches (the round-1 path; kept for A/B measurements), -1 = follow the environment variable USPACE_LN_FOLD */
+ * launches (kept for A/B measurements), -1 = back to the default.  The library reads no environment variable.
+ * A hipGraph captured by uspace_uvit_graph_create keeps the mode it was captured in. */
 USPACE_API int uspace_uvit_set_ln_fold(int mode);
+USPACE_API int uspace_uvit_get_ln_fold(void);
 /* number of N tiles (= partial-sum slots per row) a CEN_OUT launch with this [M, N] output uses */
 USPACE_API int uspace_gemm_part_slots(int M, int N);
 

@@ -267,3 +267,74 @@ def test_empty_single_and_ragged_batches(golden_dir):
     z = CNF(net).decode(x[:0], None, dissect_name="none", edit_loc=None,
                         solver_kwargs=dict(solver="fixed", solver_fix="euler", solver_fix_step=0.5))
     assert z.shape == (0, 4, 16, 16)
+
+
+def test_layernorm_fold_switch_is_part_of_the_graph_key(golden_dir):
+    """Folded and separate LayerNorm give the same forward within rounding, eagerly and through hipGraph replay, and toggling
+    the mode after a graph was captured does not replay the stale graph (the mode is in the cache key)."""
+    from uspace_amd import _hip
+    z, sd = load_sd(golden_dir, "tiny_u.npz")
+    net = build("uvit", sd, num_classes=-1, **TINY)
+    x = dev(z["x"])
+    L = _hip.lib()
+    outs = {}
+    try:
+        for fold in (1, 0, 1, 0):                 # toggled back and forth on a warm module
+            _hip.check(L.uspace_uvit_set_ln_fold(fold), "set_ln_fold")
+            assert L.uspace_uvit_get_ln_fold() == fold
+            for use in (True, False):
+                net.use_graph = use
+                o, _ = net(x, expand_t(float(z["tvals"][1]), 3), None, edit_loc=None)
+                outs.setdefault((fold, use), []).append(o)
+    finally:
+        L.uspace_uvit_set_ln_fold(-1)
+    assert L.uspace_uvit_get_ln_fold() == 1
+    for fold in (0, 1):
+        a, b = outs[(fold, True)], outs[(fold, False)]
+        assert torch.equal(a[0], a[1]) and torch.equal(b[0], b[1]) and torch.equal(a[0], b[0])   # graph == eager, per mode
+        close(a[0].cpu().numpy(), z["out1"])
+    assert not torch.equal(outs[(0, True)][0], outs[(1, True)][0])      # different launch sequences, different rounding
+    assert rel_l2(outs[(0, True)][0].cpu().numpy(), outs[(1, True)][0].cpu().numpy()) < 2e-3
+
+
+def test_data_edits_need_invalidate_packed(golden_dir):
+    """`p.data.copy_()` changes neither the version counter nor the storage: the documented contract is an explicit
+    invalidate_packed(); plain in-place edits of the parameter are still picked up by themselves."""
+    z, sd = load_sd(golden_dir, "tiny_u.npz")
+    net = build("uvit", sd, num_classes=-1, **TINY)
+    x = dev(z["x"])
+    for use in (False, True):
+        net.use_graph = use
+        a, _ = net(x, expand_t(0.3, 3), None, edit_loc=None)
+        net.decoder_pred.bias.data.add_(1.0)
+        net.invalidate_packed()
+        b, _ = net(x, expand_t(0.3, 3), None, edit_loc=None)
+        assert not torch.equal(a, b)
+        net.decoder_pred.bias.data.sub_(1.0)
+        net.repack()
+        c, _ = net(x, expand_t(0.3, 3), None, edit_loc=None)
+        assert torch.equal(a, c)
+
+
+def test_scalar_write_scale_types_and_half_precision_tail_hook(golden_dir):
+    """write_scale as np.float32 / 0-dim tensor / 0-dim array is ONE factor (the reference multiplies by it whatever its type,
+    libs/dissection.py:157); the tail hook adds on the fp32 result also for a half-precision input."""
+    zt, sd = load_sd(golden_dir, "tiny_u.npz")
+    z = np.load(os.path.join(golden_dir, "hooks_u.npz"))
+    net = build("uvit", sd, num_classes=-1, **TINY)
+    x = dev(zt["x"])
+    with tempfile.TemporaryDirectory() as d:
+        np.save(os.path.join(d, "delta_0.20.npy"), z["img_attr"])
+        base = dict(dissect_task="uspace_uvit", dissect_name="write_attr", t_edit=0.4, write_path_root=d, ith_attr=1)
+        for loc in ("head", "tail"):
+            ref, _ = net(x, expand_t(0.2, 3), None, edit_loc=loc, write_scale=0.75, **base)
+            for s in (np.float32(0.75), np.float64(0.75), torch.tensor(0.75), np.array(0.75, np.float32),
+                      np.linspace(0.0, 1.5, 3)[1]):
+                got, _ = net(x, expand_t(0.2, 3), None, edit_loc=loc, write_scale=s, **base)
+                assert torch.equal(ref, got), (loc, type(s))
+            rows, _ = net(x, expand_t(0.2, 3), None, edit_loc=loc, write_scale=[0.75, 0.75, 0.75], **base)
+            assert torch.equal(ref, rows)
+        ref, _ = net(x, expand_t(0.2, 3), None, edit_loc="tail", write_scale=0.75, **base)
+        half, _ = net(x.half(), expand_t(0.2, 3), None, edit_loc="tail", write_scale=0.75, **base)
+        assert half.dtype == torch.float16
+        close(half.float().cpu().numpy(), ref.cpu().numpy(), rel=5e-3, mx=1e-2)

@@ -26,7 +26,42 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     from uspace_amd import _hip
     assert set(_hip.SIGNATURES) == declared
-    assert _hip.lib().uspace_abi_version() == 3
+    assert _hip.lib().uspace_abi_version() == _hip.ABI_VERSION == 4
+
+
+def test_struct_layouts_agree_between_header_binding_and_integration_doc():
+    """Every struct of include/uspace_hip.h, field by field (name, C type, order): the ctypes classes of
+    uspace_amd/_hip.py, the stub tools/abi_stub.py generates, and the copy of that stub in INTEGRATION.md.
+    (Round 1 shipped an INTEGRATION.md stub with 9 of uspace_uvit_io's 10 fields.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("abi_stub", os.path.join(ROOT, "tools", "abi_stub.py"))
+    abi = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(abi)
+    from uspace_amd import _hip
+    header = dict(abi.parse_structs())
+    binding = {"uspace_uvit_config": _hip.UvitConfig, "uspace_uvit_io": _hip.UvitIO, "uspace_vae_config": _hip.VaeConfig,
+               "uspace_clip_config": _hip.ClipConfig, "uspace_gemm_ext": _hip.GemmExt}
+    assert set(header) == set(binding), "a struct of the header has no ctypes class in _hip.py (or the reverse)"
+    assert len(header["uspace_uvit_io"]) == 10 and header["uspace_uvit_io"][-1][0] == "mid_row_scale"
+    # the generated stub, executed
+    ns = {}
+    exec(abi.stub(), ns)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    a, b = doc.index(abi.BEGIN), doc.index(abi.END)
+    block = doc[a + len(abi.BEGIN):b]
+    code = block.split("```python", 1)[1].rsplit("```", 1)[0]
+    ns_doc = {}
+    exec(code, ns_doc)
+    for name, fields in header.items():
+        want = [(f, eval(expr, {"ctypes": ctypes})) for f, expr in fields]
+        for label, cls in (("_hip.py", binding[name]), ("abi_stub.py", ns[name]), ("INTEGRATION.md", ns_doc[name])):
+            got = list(cls._fields_)
+            assert [g[0] for g in got] == [w[0] for w in want], f"{label}: field names of {name}"
+            for (fn, gt), (_fn, wt) in zip(got, want):
+                assert ctypes.sizeof(gt) == ctypes.sizeof(wt) and gt._type_ == wt._type_, f"{label}: {name}.{fn}"
+            assert ctypes.sizeof(cls) == ctypes.sizeof(ns[name]), f"{label}: sizeof({name})"
+    # the worked example in INTEGRATION.md uses the generated classes, not a hand-written copy
+    assert "class IO(" not in doc and "class Cfg(" not in doc
 
 
 def test_config_queries_without_gpu():
@@ -432,3 +467,13 @@ def test_gemm_tile_planning_on_headline_shapes():
     c, rows = choice(64 * 334, 1024)
     assert c in (1, 3) and (c != 3 or (0 < rows < 64 * 334 and rows % 256 == 0))
     assert L.uspace_gemm_tile_choice(0, 64, None) < 0
+
+
+def test_hookplan_scalar_and_row_scales():
+    from uspace_amd.libs.dissection import HookPlan
+    for s in (2, 0.5, np.float32(0.5), np.float64(0.5), np.int64(2), torch.tensor(0.5), np.array(0.5), np.linspace(0, 1, 3)[1]):
+        p = HookPlan("write", "f", 0, s)
+        assert p.row_scales is None and p.scale == float(s), type(s)
+    for s in ([0.5, 1.0], np.array([0.5, 1.0]), torch.tensor([0.5, 1.0]), torch.tensor([0.5])):
+        p = HookPlan("write", "f", 0, s)
+        assert p.scale == 1.0 and p.row_scales.dtype == np.float32 and p.row_scales.ndim == 1

@@ -14,6 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libuspace_hip.so")
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_OUT_BF16 = 1, 2, 4, 8, 16
 EPI_CEN_OUT, EPI_LN_IN = 32, 64          # uspace_gemm_bf16_ext only (LayerNorm folded through the GEMMs)
 
+ABI_VERSION = 4
+
 _ERR = {-1: "USPACE_ERR_ARG", -2: "USPACE_ERR_LAUNCH", -3: "USPACE_ERR_WORKSPACE"}
 
 
@@ -63,6 +65,7 @@ SIGNATURES = {
     "uspace_fold_layernorm": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "uspace_center_rows": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "uspace_uvit_set_ln_fold": (_I, [_I]),
+    "uspace_uvit_get_ln_fold": (_I, []),
     "uspace_gemm_tile_choice": (_I, [_I, _I, ctypes.POINTER(_I)]),
     "uspace_gemm_slabs_bf16": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, ctypes.POINTER(_I), _I, _P, _P, _I, _P, _I, _P, _I, _P]),
     "uspace_layernorm_f32_bf16": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
@@ -123,8 +126,12 @@ def lib():
             fn = getattr(L, name)  # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
-        if L.uspace_abi_version() != 3:
+        if L.uspace_abi_version() != ABI_VERSION:
             raise UspaceHipError("libuspace_hip.so ABI version mismatch")
+        # the library itself reads no environment: USPACE_LN_FOLD=0 selects the separate-LayerNorm path for A/B runs
+        env = os.environ.get("USPACE_LN_FOLD")
+        if env is not None and env != "":
+            L.uspace_uvit_set_ln_fold(0 if env[0] == "0" else 1)
         _lib = L
     return _lib
 

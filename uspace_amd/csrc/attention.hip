@@ -289,13 +289,8 @@ template <int NT, int LC, bool SCALED, int NW>
 int launch_attn2(const bf16_t* qkv, const float* ks, bf16_t* out, int B, int L, int H, hipStream_t s) {
     constexpr int NP = (NT + 1) / 2;
     const size_t lds = (size_t)NT * 16 * KROW_BYTES + (size_t)NP * 32 * KROW_BYTES + (SCALED ? NT * 16 * 4 : 0);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)attention_kernel<NT, LC, SCALED, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return USPACE_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    US_TRY(us_opt_in_lds((const void*)attention_kernel<NT, LC, SCALED, NW>, 160 * 1024, lds_ok));
     hipLaunchKernelGGL((attention_kernel<NT, LC, SCALED, NW>), dim3(B * H), dim3(64 * NW), lds, s, qkv, ks, out, L, H);
     US_CHECK_LAUNCH();
     return USPACE_OK;

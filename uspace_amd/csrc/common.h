@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/uspace_hip.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -139,3 +141,16 @@ __device__ __forceinline__ void gelu_erf_batch(f32x4 (&v)[NV]) {
     } while (0)
 
 static inline int us_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Opt a kernel in to more than 64 KiB of dynamic LDS.  The attribute is per DEVICE: `done` (one per kernel, static at the
+// launch site) records the devices already served as a bit mask, so a process that drives several GPUs sets it on each
+// of them, and concurrent host threads at worst set it twice.  Devices >= 64 set it on every launch.
+static inline int us_opt_in_lds(const void* kernel, int bytes, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return USPACE_ERR_LAUNCH;
+    const uint64_t bit = (dev >= 0 && dev < 64) ? (1ull << dev) : 0;
+    if (bit && (done.load(std::memory_order_acquire) & bit)) return USPACE_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return USPACE_ERR_LAUNCH;
+    if (bit) done.fetch_or(bit, std::memory_order_release);
+    return USPACE_OK;
+}

@@ -768,13 +768,8 @@ extern "C" int uspace_output_head(const float* tok, int L, int extras, const flo
     const dim3 hgrid(us_cdiv(B * g * g, 4)), hblock(256);
     if ((D & 31) == 0 && D <= 2048) {
         const size_t lds = (size_t)64 * D + (64 + 16) * 4;
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)head_pred_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    140 * 1024) != hipSuccess)
-                return USPACE_ERR_LAUNCH;
-            attr_set = true;
-        }
+        static std::atomic<uint64_t> lds_ok{0};
+        US_TRY(us_opt_in_lds((const void*)head_pred_mfma_kernel<8>, 140 * 1024, lds_ok));
         hipLaunchKernelGGL(head_pred_mfma_kernel<8>, dim3(us_cdiv(B * g * g, 64)), dim3(256), lds, s, tok, L, extras, norm_g,
                            norm_b, dec_w, dec_b, scratch, B, C, S, p, D, eps);
     } else if (D <= 256) hipLaunchKernelGGL(head_pred_kernel<1>, hgrid, hblock, 0, s, tok, L, extras, norm_g, norm_b, dec_w, dec_b, scratch, B, C, S, p, D, eps);

@@ -3,7 +3,10 @@
 // as a fixed sequence of gfx950 kernels on the caller's stream.  No allocation, no sync:
 // the caller provides the packed-weights blob and a workspace sized by
 // uspace_uvit_workspace_bytes(); the sequence is hipGraph-capturable.
-#include <cstdlib>
+#include <atomic>
+#include <cstring>
+#include <memory>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -197,19 +200,30 @@ extern "C" int uspace_uvit_pack_weights(const uspace_uvit_config* cfg, const flo
 }
 
 namespace {
-int g_ln_fold = -1;   // -1: follow USPACE_LN_FOLD (default on)
-bool ln_fold_enabled() {
-    if (g_ln_fold >= 0) return g_ln_fold != 0;
-    const char* e = getenv("USPACE_LN_FOLD");
-    return !(e && e[0] == '0');
+// Process-wide switch (documented in the header's global-state note): LayerNorm folded through the GEMMs (default) or
+// separate LayerNorm launches.  No environment variable is read here; the Python binding forwards USPACE_LN_FOLD.
+std::atomic<int> g_ln_fold{1};
+
+// Derived per-configuration layout (parameter offsets in the blob): built once per distinct configuration.
+std::mutex g_model_mu;
+std::vector<std::pair<uspace_uvit_config, std::shared_ptr<const Model>>> g_models;
+std::shared_ptr<const Model> model_for(const uspace_uvit_config& c) {
+    std::lock_guard<std::mutex> lock(g_model_mu);
+    for (const auto& e : g_models)
+        if (memcmp(&e.first, &c, sizeof(c)) == 0) return e.second;
+    if (g_models.size() >= 16) g_models.erase(g_models.begin());
+    g_models.emplace_back(c, std::make_shared<const Model>(build_model(c)));
+    return g_models.back().second;
 }
 }  // namespace
 
 extern "C" int uspace_uvit_set_ln_fold(int mode) {
     if (mode < -1 || mode > 1) return USPACE_ERR_ARG;
-    g_ln_fold = mode;
+    g_ln_fold.store(mode < 0 ? 1 : mode);
     return USPACE_OK;
 }
+
+extern "C" int uspace_uvit_get_ln_fold(void) { return g_ln_fold.load(); }
 
 extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* blob, void* workspace,
                                    size_t workspace_bytes, const uspace_uvit_io* io, int B, uspace_stream_t stream) {
@@ -217,7 +231,8 @@ extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* bl
     if (!io->x || !io->t || !io->out) return USPACE_ERR_ARG;
     if (cfg->n_extra > 0 && !io->context) return USPACE_ERR_ARG;
     const uspace_uvit_config& c = *cfg;
-    const Model m = build_model(c);
+    const std::shared_ptr<const Model> mp = model_for(c);
+    const Model& m = *mp;
     const Workspace w = plan_workspace(c, m, B);
     if (workspace_bytes < w.total) return USPACE_ERR_WORKSPACE;
 
@@ -236,7 +251,7 @@ extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* bl
     uint16_t* xc = (uint16_t*)(ws + w.xc);
     float* part = (float*)(ws + w.part);
     float* cbuf = (float*)(ws + w.cbuf);
-    const bool fold = ln_fold_enabled() && uspace_gemm_part_slots(B * m.L, c.embed_dim) <= 8;   // consumers read <= 8 partial slots per row
+    const bool fold = g_ln_fold.load() != 0 && uspace_gemm_part_slots(B * m.L, c.embed_dim) <= 8;   // consumers read <= 8 partial slots per row
     const size_t MD = (size_t)M * D;
 
     constexpr int B_ = USPACE_EPI_BIAS, G_ = USPACE_EPI_GELU, R_ = USPACE_EPI_RESIDUAL, F_ = USPACE_EPI_OUT_F32,

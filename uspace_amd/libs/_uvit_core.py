@@ -71,7 +71,7 @@ class UViTBase(nn.Module):
         self._workspace = {}         # B -> uint8 tensor
         self._delta_cache = {}
         self.use_graph = True        # replay a captured hipGraph for plain (un-hooked) evaluations
-        self._graphs = {}            # (B, device, blob ptr, has ctx) -> _GraphEntry (at most _MAX_GRAPHS)
+        self._graphs = {}            # (B, device, blob ptr, has ctx, LN-fold mode) -> _GraphEntry (at most _MAX_GRAPHS)
 
     # ------------------------------------------------------------------ parameter tree
     def _build_tree(self, extra_builder):
@@ -196,6 +196,18 @@ class UViTBase(nn.Module):
         self._packed = (device, versions, blob)
         return blob
 
+    def invalidate_packed(self):
+        """Forget the packed bf16 weight blob (and the hipGraphs captured over it): the next forward repacks from the
+        parameters.  Needed only after IN-PLACE edits through ``p.data`` (``p.data.copy_(w)``, ``p.data.mul_()``), which
+        change neither the parameter's version counter nor its storage -- the two things ``_packed_blob`` watches;
+        ``load_state_dict``, ``.to()``, optimiser steps and plain in-place ops on the parameter are picked up by itself."""
+        self._packed = None
+        for ent in self._graphs.values():
+            ent.destroy()
+        self._graphs = {}
+
+    repack = invalidate_packed
+
     def _workspace_for(self, B, device):
         key = (B, str(device))
         ws = self._workspace.get(key)
@@ -209,7 +221,8 @@ class UViTBase(nn.Module):
     _MAX_GRAPHS = 4
 
     def _graph_entry(self, B, dev, blob, context):
-        key = (B, str(dev), blob.data_ptr(), context is not None)
+        # a captured graph replays the launch sequence of the LayerNorm mode it was captured in
+        key = (B, str(dev), blob.data_ptr(), context is not None, _hip.lib().uspace_uvit_get_ln_fold())
         ent = self._graphs.get(key)
         if ent is not None:
             return ent
@@ -257,14 +270,16 @@ class UViTBase(nn.Module):
 
     # ------------------------------------------------------------------ the single HIP call
     def _run(self, x, timesteps, context=None, mid_delta=None, mid_scale=0.0, mid_tap=None, key_scale=None,
-             mid_row_scale=None):
+             mid_row_scale=None, keep_f32=False):
+        """``keep_f32``: return the fp32 result even for a half-precision ``x`` (the caller still has fp32 work to do)."""
         _hip.require_device(x, "x")
         if x.dim() != 4 or x.shape[1] != self.in_chans or x.shape[2] != self.img_size or x.shape[3] != self.img_size:
             raise ValueError(f"x must be [B,{self.in_chans},{self.img_size},{self.img_size}], got {tuple(x.shape)}")
         B = x.shape[0]
         dev = x.device
         if B == 0:                                  # empty batch: the reference returns an empty prediction
-            return torch.empty(0, self.in_chans, self.img_size, self.img_size, dtype=x.dtype, device=dev)
+            return torch.empty(0, self.in_chans, self.img_size, self.img_size,
+                               dtype=torch.float32 if keep_f32 else x.dtype, device=dev)
         xin = x.detach().to(torch.float32).contiguous()
         t = timesteps
         if not torch.is_tensor(t):
@@ -280,7 +295,7 @@ class UViTBase(nn.Module):
                 t = t.contiguous(); t_stride = 1
         plain = mid_delta is None and mid_tap is None and key_scale is None
         if self.use_graph and plain and t_stride == 0:
-            return self._run_graph(xin, t, context, B, dev, x.dtype)
+            return self._run_graph(xin, t, context, B, dev, torch.float32 if keep_f32 else x.dtype)
         out = torch.empty(B, self.in_chans, self.img_size, self.img_size, dtype=torch.float32, device=dev)
         blob = self._packed_blob(dev)
         ws = self._workspace_for(B, dev)
@@ -289,7 +304,7 @@ class UViTBase(nn.Module):
                          _hip.ptr(mid_row_scale))
         _hip.check(_hip.lib().uspace_uvit_forward(ctypes.byref(self._cfg), _hip.ptr(blob), _hip.ptr(ws), ws.numel(),
                                                   ctypes.byref(io), B, _hip.stream_ptr()), "uspace_uvit_forward")
-        return out if x.dtype == torch.float32 else out.to(x.dtype)
+        return out if (keep_f32 or x.dtype == torch.float32) else out.to(x.dtype)
 
 
 class _GraphEntry:

@@ -142,6 +142,11 @@ class FrozenAutoencoderKL(nn.Module):
         return super().load_state_dict(sd, strict=strict)
 
     # ------------------------------------------------------------------ HIP decode
+    def invalidate_packed(self):
+        """Forget the packed weight blob; needed only after in-place edits through ``p.data`` (same contract as
+        UViT.invalidate_packed)."""
+        self._packed = None
+
     def _packed_blob(self, device):
         ps = list(self.parameters())
         versions = tuple((p.data_ptr(), p._version) for p in ps)

@@ -116,6 +116,11 @@ class CLIPTextTransformer(nn.Module):
         c = self.cfg
         return _hip.ClipConfig(c["vocab"], c["dim"], c["heads"], c["layers"], c["ffn"], c["max_pos"], c["eps"])
 
+    def invalidate_packed(self):
+        """Forget the packed weight blob; needed only after in-place edits through ``p.data`` (same contract as
+        UViT.invalidate_packed)."""
+        self._packed = None
+
     def _packed_blob(self, device):
         ps = list(self.parameters())
         versions = tuple((p.data_ptr(), p._version) for p in ps)

@@ -6,6 +6,7 @@ control plane the reference keys on the formatted timestep: which file, which ro
 this step edits at all.  Direction tables are read from disk once and kept resident on the
 device instead of being re-loaded at every ODE step.
 """
+import numbers
 import os
 
 import numpy as np
@@ -47,7 +48,13 @@ class HookPlan:
 
     def __init__(self, kind, path=None, ith=None, scale=0.0):
         self.kind, self.path, self.ith = kind, path, ith
-        if isinstance(scale, (int, float)):
+        # the reference multiplies by whatever `write_scale` is (libs/dissection.py:157): Python numbers, numpy scalars
+        # (an element of np.linspace), 0-dim arrays and 0-dim tensors are all ONE factor for the whole batch
+        if torch.is_tensor(scale) and scale.dim() == 0:
+            scale = float(scale.item())
+        elif isinstance(scale, np.ndarray) and scale.ndim == 0:
+            scale = float(scale)
+        if isinstance(scale, numbers.Real) or isinstance(scale, (np.floating, np.integer)):
             self.scale, self.row_scales = float(scale), None
         else:
             self.scale = 1.0

@@ -82,16 +82,20 @@ class UViT(UViTBase):
             else:
                 mid_delta = self._deltas().get(plan.path, plan.ith, dev, self.seq_len * self.embed_dim)
                 mid_scale = plan.scale
+        tail_write = plan is not None and edit_loc == "tail" and plan.kind == "write"
         out = self._run(x, timesteps, context=label_tok, mid_delta=mid_delta, mid_scale=mid_scale, mid_tap=mid_tap,
-                        mid_row_scale=rows if mid_delta is not None else None)
+                        mid_row_scale=rows if mid_delta is not None else None, keep_f32=tail_write)
         if mid_tap is not None:
             dissection.save_activation(plan.path, mid_tap, kwargs)
         if plan is not None and edit_loc == "tail":
             if plan.kind == "read":
                 dissection.save_activation(plan.path, out, kwargs)
             else:
+                # the add runs on the fp32 result, the cast back to a half-precision x.dtype comes last
                 delta = self._deltas().get(plan.path, plan.ith, dev, out[0].numel())
                 out = _hip.add_broadcast(out, delta, plan.scale, row_scale=rows)
+                if out.dtype != x.dtype:
+                    out = out.to(x.dtype)
         return out, None
 
     def _deltas(self):
