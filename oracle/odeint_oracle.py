@@ -120,7 +120,7 @@ def solve(f, y0, t0, t1, method="dopri5", rtol=1e-5, atol=1e-5, step_size=None, 
     h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
     f1 = g(t0 + h0, _lin(y, [f0], [h0]))
     d2 = _rms((f1 - f0) / scale0) / h0
-    h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** (1.0 / (order + 1))
+    h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** (1.0 / order)   # torchdiffeq passes order - 1 to its heuristic
     h = min(100 * h0, h1)
     t = t0
     counters["accepted"] = counters["rejected"] = 0

@@ -270,3 +270,33 @@ def test_pca_directions_on_device_match_reference_golden(golden_dir, tmp_path):
     same_up_to_sign(np.load(tmp_path / f"pca{n}_0.50.npy"))
     with pytest.raises(ValueError):
         pca_components(x, len(feats) + 1)
+
+
+def test_group_controlled_error_norm_on_the_device():
+    """HipStateOps(group=...) all-reduces (sum of squares, count) over RCCL instead of reading the local RMS: with one
+    rank the solve must take exactly the steps of the plain solve (the 2-rank behaviour is covered on CPU by
+    tests/test_sharded_sampling.py); CNF.norm_group routes it."""
+    import torch.distributed as dist
+
+    from uspace_amd.odeint import HipStateOps, Stats, odeint
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        rng = np.random.default_rng(3)
+        y0 = torch.from_numpy(rng.standard_normal((5, 4, 8, 8)).astype(np.float32)).cuda()
+        s0, s1 = Stats(), Stats()
+        a = odeint(_field_torch, y0, 0.0, 1.0, method="dopri5", stats=s0)
+        b = odeint(_field_torch, y0, 0.0, 1.0, method="dopri5", stats=s1, ops=HipStateOps(y0, group=True))
+        assert (s0.nfe, s0.accepted, s0.rejected) == (s1.nfe, s1.accepted, s1.rejected)
+        assert float((a - b).abs().max()) < 1e-5
+        # an empty shard still walks the control loop (it owes the group its share of every norm)
+        s2 = Stats()
+        e = odeint(_field_torch, y0[:0], 0.0, 1.0, method="dopri5", stats=s2, ops=HipStateOps(y0, group=True))
+        assert e.shape[0] == 0 and s2.nfe > 0
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -20,6 +20,10 @@ class CNFBase(nn.Module):
         self.net = net
         self.last_stats = None        # odeint.Stats of the most recent solve (NFE etc.)
         self.state_ops_factory = None  # None -> odeint.HipStateOps (the only implementation shipped)
+        # adaptive step control over a batch sharded across ranks: None = every rank controls its own steps
+        # (the reference's behaviour under `accelerate launch`); a process group, or True for the default group = one
+        # all-reduced error norm per step attempt, i.e. the step sequence of the unsharded solve on every rank
+        self.norm_group = None
 
     # ------------------------------------------------------------------ reference surface
     def is_dissection_mode(self, kwargs):
@@ -66,7 +70,13 @@ class CNFBase(nn.Module):
     def _integrate(self, func, y0, t0, t1, ode_kwargs, n_steps=None):
         stats = self.last_stats if self.last_stats is not None else Stats()
         opts = ode_kwargs.get("options") or {}
-        ops = self.state_ops_factory(y0) if self.state_ops_factory is not None else None
+        if self.state_ops_factory is not None:
+            ops = self.state_ops_factory(y0)
+        elif self.norm_group is not None:
+            from .odeint import HipStateOps
+            ops = HipStateOps(y0, group=self.norm_group)
+        else:
+            ops = None
         out = odeint(func, y0, float(t0), float(t1), method=ode_kwargs["method"], rtol=ode_kwargs["rtol"],
                      atol=ode_kwargs["atol"], step_size=opts.get("step_size"), n_steps=n_steps, stats=stats, ops=ops)
         self.last_stats = stats

@@ -66,10 +66,27 @@ class Stats:
         self.rejected = 0
 
 
-class HipStateOps:
-    """fp32 device-tensor arithmetic through libuspace_hip.so."""
+def allreduce_mean_square(pair, group=None):
+    """Global mean of squares from each rank's ``pair`` = [sum of squares, element count] (a 2-element fp64 tensor on the
+    rank's device): ONE small all-reduce; returns a host float.  It is the only collective of an error-controlled solve
+    run with a process group (option B): every rank then takes the accept / reject decisions and the step
+    sizes of the single-process solve over the whole batch.  ``group`` None or True = the default group."""
+    import torch.distributed as dist
 
-    def __init__(self, like):
+    dist.all_reduce(pair, op=dist.ReduceOp.SUM, group=None if group is True else group)
+    tot, n = float(pair[0].item()), float(pair[1].item())
+    return tot / n if n > 0 else 0.0
+
+
+class HipStateOps:
+    """fp32 device-tensor arithmetic through libuspace_hip.so.
+
+    ``group``: a torch.distributed process group (or True for the default group).  With it the RMS norms that steer an
+    adaptive solve are taken over the batch of ALL ranks, so a batch sharded over GPUs follows the step sequence of the
+    unsharded solve; without it (default) every rank controls its own steps, as the reference does under
+    ``accelerate launch`` (each rank solves its own mini-batch, tools/utils_uvit.py:269-277)."""
+
+    def __init__(self, like, group=None):
         import torch
 
         from . import _hip
@@ -79,6 +96,8 @@ class HipStateOps:
         self._torch = torch
         self._scratch = torch.empty(1024, dtype=torch.float32, device=like.device)
         self._result = torch.empty(1, dtype=torch.float32, device=like.device)
+        self.group = group
+        self._pair = torch.zeros(2, dtype=torch.float64, device=like.device) if group is not None else None
 
     def prepare(self, y):
         return y.detach().to(self._torch.float32).contiguous()
@@ -86,12 +105,21 @@ class HipStateOps:
     def combine(self, y, ks, coefs):
         """y + sum_i coefs[i] * ks[i] into a fresh tensor."""
         out = self._torch.empty_like(y)
+        if y.numel() == 0:
+            return out
         return self._hip.ode_combine(out, y, ks, coefs)
 
     def scaled_norm(self, y0, y1, ks, coefs, rtol, atol):
         """sqrt(mean((sum_i c_i k_i / (atol + rtol*max(|y0|,|y1|)))^2)) as a host float (one sync)."""
-        self._hip.ode_error_norm(y0, y1, ks, coefs, rtol, atol, self._scratch, self._result)
-        return float(self._result.item())
+        n = y0.numel()
+        if n > 0:
+            self._hip.ode_error_norm(y0, y1, ks, coefs, rtol, atol, self._scratch, self._result)
+        if self.group is None:
+            return float(self._result.item())
+        # (sum of squares, count) of this rank -> global RMS
+        self._pair[0] = (self._result[0].double() ** 2) * n if n > 0 else 0.0
+        self._pair[1] = float(n)
+        return math.sqrt(allreduce_mean_square(self._pair, self.group))
 
 
 def _call(func, t, y, sign, stats):
@@ -147,7 +175,10 @@ def odeint(func, y0, t0, t1, *, method="dopri5", rtol=1e-5, atol=1e-5, step_size
                               rejection ("dopri5-50" of BASELINE.md: 1 + 6*n NFE)
     """
     stats = stats if stats is not None else Stats()
-    if hasattr(y0, "numel") and y0.numel() == 0:      # empty batch: nothing to integrate (torchdiffeq returns y0's shape)
+    grouped = getattr(ops, "group", None) is not None
+    if hasattr(y0, "numel") and y0.numel() == 0 and not (grouped and method in ADAPTIVE and n_steps is None):
+        # empty batch: nothing to integrate (torchdiffeq returns y0's shape).  A rank with an empty shard of a group-controlled
+        # adaptive solve still walks the control loop: it owes the other ranks its (zero) share of every norm.
         if method not in FIXED and method not in ADAPTIVE:
             raise NotImplementedError(f"method={method}")
         return y0.clone()
@@ -197,7 +228,9 @@ def odeint(func, y0, t0, t1, *, method="dopri5", rtol=1e-5, atol=1e-5, step_size
     y_probe = ops.combine(y, [f0], [h0])
     f_probe = f_eval(t0 + h0, y_probe)
     d2 = ops.scaled_norm(y, y, [f_probe, f0], [1.0, -1.0], rtol, atol) / h0
-    h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** (1.0 / (order + 1))
+    # torchdiffeq hands `order - 1` to its initial-step heuristic (rk_common.py: _select_initial_step(..., self.order - 1,
+    # ...)), whose exponent is 1 / (that + 1): 1/5 for dopri5, not Hairer's 1/(order + 1)
+    h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** (1.0 / order)
     dt = min(100 * h0, h1)
 
     t = t0
