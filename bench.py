@@ -110,18 +110,44 @@ def cpu_baseline(model_key, nfe, budget_s=12.0):
                        f"extrapolated linearly to {nfe} NFE per solve; host {os.cpu_count()} logical CPUs")
 
 
+# BASELINE.json configs[i-1] -> workload; "dopri5" = 50 fixed Dormand-Prince steps (301 NFE), "euler" = 50 Euler steps
+CONFIGS = {
+    1: dict(model="S_u", batch=4, solver="euler", ode_steps=20, hook=False),
+    2: dict(model="L_u", batch=64, solver="dopri5", ode_steps=50, hook=False),      # the headline
+    3: dict(model="L_t", batch=64, solver="euler", ode_steps=50, hook=False),
+    4: dict(model="S_t", batch=64, solver="euler", ode_steps=50, hook=False),       # 512 over 8 GPUs
+    5: dict(model="L_u", batch=32, solver="euler", ode_steps=50, hook=True),        # 256 over 8 GPUs, mid-block u-space write hook
+}
+
+
+def hook_kwargs(net, tmpdir):
+    """Synthetic direction tables of SURVEY.md 8(d): delta_{t:.2f}.npy [40, L, D] ~ N(0, 0.01^2), seed 11."""
+    rng = np.random.default_rng(11)
+    table = (rng.standard_normal((40, net.seq_len, net.embed_dim)) * 0.01).astype(np.float32)
+    for k in range(1, 101):
+        np.save(os.path.join(tmpdir, f"delta_{k / 100:.2f}.npy"), table)
+    return dict(dissect_task="uspace_uvit", dissect_name="write_attr", edit_loc="mid", t_edit=0.4, write_scale=1.0,
+                ith_attr="31_39_20", write_path_root=tmpdir)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--model", default="L_u", choices=sorted(MODELS))
-    ap.add_argument("--batch", type=int, default=64, help="latents per GPU")
-    ap.add_argument("--solver", default="dopri5", choices=["dopri5", "euler"])
-    ap.add_argument("--ode-steps", type=int, default=50)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[N-1]; 2 = the headline")
+    ap.add_argument("--model", default=None, choices=sorted(MODELS))
+    ap.add_argument("--batch", type=int, default=None, help="latents per GPU")
+    ap.add_argument("--solver", default=None, choices=["dopri5", "euler"])
+    ap.add_argument("--ode-steps", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the auxiliary Euler-50 measurement")
+    ap.add_argument("--no-extra", action="store_true", help="skip the auxiliary Euler-50 / VAE / roofline measurements")
     args = ap.parse_args()
+    wl = dict(CONFIGS[args.config])
+    for k in ("model", "batch", "solver", "ode_steps"):
+        if getattr(args, k) is not None:
+            wl[k] = getattr(args, k)
+    args.model, args.batch, args.solver, args.ode_steps = wl["model"], wl["batch"], wl["solver"], wl["ode_steps"]
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started as plain `python bench.py --gpus N`: re-launch as one rank per GPU (what the driver does itself)
@@ -159,12 +185,14 @@ def main():
         from uspace_amd.flow_matching_t2i import CNF
     else:
         from uspace_amd.flow_matching import CNF
-    net.use_graph = False      # eager launches: the roofline line records HIP events around individual GEMM launches
-    cnf = CNF(net)
+    cnf = CNF(net)                                             # product defaults: hipGraph replay of plain evaluations
     B = args.batch
     g = torch.Generator().manual_seed(7 + rank)
     z = torch.randn(B, 4, 32, 32, generator=g).to(dev)
     cond = torch.randn(B, 77, 768, generator=g).to(dev) if t2i else None
+    import tempfile
+    tmp = tempfile.TemporaryDirectory()
+    hk = hook_kwargs(net, tmp.name) if wl["hook"] else None
 
     def solver_kwargs(kind):
         sk = dict(solver_fix="euler", solver_fix_step=1.0 / args.ode_steps, solver_adaptive="dopri5",
@@ -174,6 +202,8 @@ def main():
 
     def solve(kind):
         kw = dict(dissect_name="bench", edit_loc=None, solver_kwargs=solver_kwargs(kind))
+        if hk:
+            kw.update(hk)
         out = cnf.decode(z, cond, **kw) if t2i else cnf.decode(z, None, **kw)
         return gather_batch(out, B * world)                   # the one collective of the sampling path
 
@@ -186,25 +216,42 @@ def main():
     with torch.no_grad():
         for _ in range(args.warmup):
             solve(args.solver)
-        # roofline of the dominant kernel: fc1 GEMM (+bias +GELU -> bf16), timed by HIP events on its own stream
-        D, Hd = cfg["embed_dim"], 4 * cfg["embed_dim"]
-        fold = _hip.lib().uspace_uvit_get_ln_fold() != 0       # norm2 folded into fc1 (default) or a separate launch
-        fc1_flags = _hip.EPI_BIAS | _hip.EPI_GELU | _hip.EPI_OUT_BF16 | (_hip.EPI_LN_IN if fold else 0)
-        if rank == 0:
-            _hip.prof_gemm_begin(fc1_flags, Hd, D, 8192)
+        # ---- the timed region: exactly `steps` solves between two fences; every solve also bracketed by HIP events on
+        #      the stream the kernels run on (torch's current stream is the one handed to the C-ABI)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
         fence()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for i in range(args.steps):
+            ev[i][0].record()
             res = solve(args.solver)
+            ev[i][1].record()
         fence()
         dt = time.perf_counter() - t0
         nfe = cnf.last_stats.nfe
-        fc1_ms, fc1_n = _hip.prof_gemm_end() if rank == 0 else (0.0, 0)
+        per_solve_ms = sorted(a.elapsed_time(b) for a, b in ev)
+        median_ms = per_solve_ms[len(per_solve_ms) // 2]
         assert bool(torch.isfinite(res).all())
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt, median_ms], dtype=torch.float64, device=dev)
         if world > 1:
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, median_ms = float(tt[0].item()), float(tt[1].item())
+
+        # ---- outside the timed region: roofline of the dominant kernel.  One more solve with eager launches and HIP
+        #      events recorded (by the library, on the launching stream) around every fc1 launch
+        D, Hd = cfg["embed_dim"], 4 * cfg["embed_dim"]
+        fold = _hip.lib().uspace_uvit_get_ln_fold() != 0       # norm2 folded into fc1 (default) or a separate launch
+        fc1_flags = _hip.EPI_BIAS | _hip.EPI_GELU | _hip.EPI_OUT_BF16 | (_hip.EPI_LN_IN if fold else 0)
+        fc1_ms, fc1_n, peaks = 0.0, 0, None
+        if rank == 0 and not args.no_extra:
+            net.use_graph = False
+            _hip.prof_gemm_begin(fc1_flags, Hd, D, 8192)
+            solve(args.solver)
+            torch.cuda.synchronize()
+            fc1_ms, fc1_n = _hip.prof_gemm_end()
+            net.use_graph = True
+            peaks = _hip.prof_peaks()
+        if world > 1:
+            dist.barrier()
 
         extra = {}
         if not args.no_extra and args.solver == "dopri5":
@@ -246,11 +293,14 @@ def main():
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.model} (U-ViT D={D} depth={cfg['depth']} L={L}), batch {B}/GPU, "
-                                   f"{args.solver}-{args.ode_steps} fixed steps, seeded random-init weights, "
-                                   f"latent->latent (VAE excluded)",
+            "config": {"workload": f"BASELINE configs[{args.config - 1}]: {args.model} (U-ViT D={D} depth={cfg['depth']} L={L}), "
+                                   f"batch {B}/GPU, {args.solver}-{args.ode_steps} fixed steps"
+                                   + (", mid-block u-space write hook (t <= 0.4)" if wl["hook"] else "")
+                                   + ", seeded random-init weights, latent->latent (VAE excluded), hipGraph replay per evaluation",
                        "global_batch": B * world, "nfe_per_solve": nfe, "parallelism": f"batch-sharded x{world}"},
             "nfe": nfe,
+            "median_ms_per_step": median_ms, "per_step_ms_rank0": per_solve_ms,
+            "images_per_sec_median": B * world / (median_ms * 1e-3),
             "sample_nfe_per_sec": B * world * nfe * args.steps / dt,
             "model_tflops_per_gpu": fps * B * nfe * args.steps / dt / 1e12,
             "mfma_util_whole_solve": fps * B * nfe * args.steps / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS,
@@ -262,18 +312,34 @@ def main():
             ach = flops / avg_s / 1e12
             traffic = None
             tp = os.path.join(ROOT, "profiles", "fc1_traffic.json")
-            if os.path.exists(tp):
+            if os.path.exists(tp) and args.model == "L_u" and B == 64:
                 traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
             line["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<256,256,2,4," + ("LN_IN|" if fold else "") + "BIAS|GELU|OUT_BF16> (fc1)",
                                 "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
-                                "launches": fc1_n, "avg_us": 1e6 * avg_s, "flops_per_launch": flops}
+                                "launches": fc1_n, "avg_us": 1e6 * avg_s, "flops_per_launch": flops,
+                                "timing": "HIP events around every fc1 launch of one extra eager solve after the timed region"}
+            if peaks:
+                line["roofline"]["peak_measured"] = {"mfma_bf16_tflops": peaks[0], "hbm_copy_gbs": peaks[1],
+                                                     "frac_of_measured_mfma": ach / peaks[0],
+                                                     "how": "MFMA-only loop on every SIMD; 1 GiB device-to-device float4 copy (read + write bytes)"}
         if not args.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline(args.model, nfe)
+                rp = os.path.join(ROOT, "tests", "golden", "ref_cpu_timing.json")
+                if os.path.exists(rp) and args.config in (1, 2):
+                    r = json.load(open(rp))
+                    key = {1: "cfg1_images_per_s", 2: "cfg2_L_u_B64_dopri5_50_images_per_s_extrapolated" if args.solver == "dopri5"
+                           else "cfg2_L_u_B64_euler50_images_per_s_extrapolated"}[args.config]
+                    line["cpu_baseline"]["reference_pytorch_cpu"] = {
+                        "value": r[key], "unit": "images/sec", "cores": r["threads"], "kind": "reference",
+                        "host": f"build container, {r['cpu']}, {r['nproc']} CPUs (NOT this GPU host; the reference cannot travel)",
+                        "sample": "the reference's own PyTorch-CPU fp32 forward timed by tests/golden/make_golden.py"
+                                  + (" at batch 8 and extrapolated linearly in batch and NFE" if args.config == 2 else "")}
             except Exception as ex:  # the baseline is reported context, never fatal
                 line["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(line))
+    tmp.cleanup()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

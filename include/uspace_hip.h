@@ -339,6 +339,12 @@ USPACE_API int uspace_quick_gelu_bf16(uint16_t* x, long n, uspace_stream_t strea
 USPACE_API int uspace_prof_gemm_begin(int epi_flags, int N, int K, int max_launches);
 USPACE_API int uspace_prof_gemm_end(double* total_ms, int* n_launches);
 
+/* What this box reaches on the two rooflines (synchronous, self-timed with HIP events, own scratch; host pointers out):
+ * dense bf16 MFMA rate of an MFMA-only loop on every SIMD (TFLOP/s), and a device-to-device float4 stream copy
+ * (read + written bytes per second, GB/s) over `bytes` (>= 1 MiB) repeated `reps` times. */
+USPACE_API int uspace_prof_mfma_peak(int iters, double* tflops);
+USPACE_API int uspace_prof_hbm_copy(size_t bytes, int reps, double* gb_per_s);
+
 #ifdef __cplusplus
 }
 #endif

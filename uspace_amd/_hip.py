@@ -108,6 +108,8 @@ SIGNATURES = {
     "uspace_quick_gelu_bf16": (_I, [_P, _L, _P]),
     "uspace_prof_gemm_begin": (_I, [_I, _I, _I, _I]),
     "uspace_prof_gemm_end": (_I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I)]),
+    "uspace_prof_mfma_peak": (_I, [_I, ctypes.POINTER(ctypes.c_double)]),
+    "uspace_prof_hbm_copy": (_I, [_SZ, _I, ctypes.POINTER(ctypes.c_double)]),
 }
 
 _lib = None
@@ -261,6 +263,14 @@ def ode_error_norm(y0, y1, ks, coefs, rtol, atol, scratch, result):
 
 def prof_gemm_begin(epi_flags, N, K, max_launches=8192):
     check(lib().uspace_prof_gemm_begin(epi_flags, N, K, max_launches), "uspace_prof_gemm_begin")
+
+
+def prof_peaks(mfma_iters=20000, copy_bytes=1 << 30, copy_reps=10):
+    """(dense bf16 MFMA TFLOP/s of an MFMA-only loop, stream-copy GB/s read + write) measured on the current device."""
+    tf, gb = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    check(lib().uspace_prof_mfma_peak(mfma_iters, ctypes.byref(tf)), "uspace_prof_mfma_peak")
+    check(lib().uspace_prof_hbm_copy(copy_bytes, copy_reps, ctypes.byref(gb)), "uspace_prof_hbm_copy")
+    return tf.value, gb.value
 
 
 def prof_gemm_end():
