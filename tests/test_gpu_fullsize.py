@@ -157,3 +157,113 @@ def test_config3_and_4_t2i_shapes_run_and_slice_consistently():
         assert bool(torch.isfinite(e).all()) and not torch.equal(e, p)
         del net
         torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Full-size forwards against the CPU oracle on sampled batch rows (rows are independent; the oracle does a pair of L-size
+# samples in under a second on the GPU host).  These are the only end-to-end checks of the 256 x 256 + strip tile plans
+# (the reference goldens are batch 2) -- VERDICT r1 "weak / parity" item 2.
+# ------------------------------------------------------------------------------------------------------------------
+ROWS = (0, 31, 63)
+FWD_TOL = 1e-2            # the tolerance contract of DESIGN.md: one forward rel-L2 <= 1e-2 against the fp32 oracle
+
+
+def _oracle_rows(net, spec_kw, x, tval, rows, context=None, **kw):
+    from oracle import uvit_oracle as O
+    spec = O.UViTSpec(img_size=32, patch_size=2, in_chans=4, **spec_kw)
+    sd = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    idx = torch.tensor(rows)
+    ctx = context[idx].cpu().numpy() if context is not None else None
+    return O.uvit_forward(spec, sd, x[idx].cpu().numpy(), np.full(len(rows), tval, np.float32), context=ctx, **kw)
+
+
+def test_config2_rows_match_oracle(net_L_u):
+    z = _z(64)
+    out, _ = net_L_u(z, _t(0.35, 64), None, edit_loc=None)
+    ref = _oracle_rows(net_L_u, L_CFG, z, 0.35, ROWS, edit_loc=None)
+    got = out[torch.tensor(ROWS)].cpu().numpy()
+    for k, r in enumerate(ROWS):
+        e = rel_l2(got[k], ref[k])
+        assert e <= FWD_TOL, (r, e)
+    assert rel_l2(got, ref) <= FWD_TOL
+
+
+@pytest.mark.parametrize("cfg", [L_CFG, S_CFG], ids=["L_t", "S_t"])
+def test_config3_and_4_rows_match_oracle(cfg):
+    from uspace_amd.tools.utils_uvit import get_nnet
+    torch.manual_seed(1234)
+    net = get_nnet("uvit_t2i", clip_dim=768, num_clip_token=77, **COMMON, **cfg).cuda().eval()
+    g = torch.Generator().manual_seed(7)
+    z = torch.randn(64, 4, 32, 32, generator=g).cuda()
+    ctx = torch.randn(64, 77, 768, generator=g).cuda()
+    out, _ = net(z, _t(0.5, 64), context=ctx)
+    ref = _oracle_rows(net, dict(cfg, t2i=True), z, 0.5, ROWS, context=ctx)
+    assert rel_l2(out[torch.tensor(ROWS)].cpu().numpy(), ref) <= FWD_TOL
+    # one prompt-to-prompt edit at L = 334: a different multiplier per row, every block, t below t_edit
+    ids = [np.array([2 + (b % 5), 9, 40]) for b in range(64)]
+    kw = dict(dissect_name="p2p", fm_direction="decode", t_edit=0.5, block_id="all",
+              token_kwargs=dict(token_dissect="p2p_rescale", p2p_multiplier=8.0))
+    e, _ = net(z, _t(0.3, 64), context=ctx, target_context_ids=ids, **kw)
+    ref_e = _oracle_rows(net, dict(cfg, t2i=True), z, 0.3, ROWS, context=ctx, target_context_ids=[ids[r] for r in ROWS], **kw)
+    ref_p = _oracle_rows(net, dict(cfg, t2i=True), z, 0.3, ROWS, context=ctx)
+    got_e = e[torch.tensor(ROWS)].cpu().numpy()
+    assert rel_l2(got_e, ref_e) <= FWD_TOL
+    # the edit itself is reproduced: its effect is several times the bf16 noise floor of a forward (about 5e-3)
+    assert rel_l2(ref_e, ref_p) > 1e-2 and rel_l2(got_e - ref_p, ref_e - ref_p) < 0.35
+    del net
+    torch.cuda.empty_cache()
+
+
+def test_config5_mid_hook_rows_match_oracle(net_L_u):
+    """BASELINE config 5's per-GPU share: U-ViT-L, batch 32, u-space write hook at the mid block."""
+    rng = np.random.default_rng(11)
+    table = (rng.standard_normal((40, 257, 1024)) * 1.5).astype(np.float32)
+    z = _z(32)
+    rows = (0, 17, 31)
+    with tempfile.TemporaryDirectory() as d:
+        np.save(os.path.join(d, "delta_0.20.npy"), table)
+        kw = dict(dissect_task="uspace_uvit", dissect_name="write_attr", t_edit=0.4, write_path_root=d, edit_loc="mid",
+                  ith_attr="31_39_20", write_scale=2.0)
+        out, _ = net_L_u(z, _t(0.2, 32), None, **kw)
+        ref = _oracle_rows(net_L_u, L_CFG, z, 0.2, rows, **kw)
+        plain = _oracle_rows(net_L_u, L_CFG, z, 0.2, rows, edit_loc=None)
+    got = out[torch.tensor(rows)].cpu().numpy()
+    assert rel_l2(got, ref) <= FWD_TOL
+    assert rel_l2(ref, plain) > 1e-2 and rel_l2(got - plain, ref - plain) < 0.35
+
+
+def test_layernorm_fold_survives_large_row_means():
+    """Whole-network stress of the folded LayerNorm: pos_embed x50 and constant proj / fc2 / skip biases
+    make every token's mean dwarf its standard deviation and shift it at every sublayer -- the situation of outlier channels
+    in trained U-ViTs, where a variance taken as E[(x-c)^2] - d^2 would lose bits if c tracked the mean badly.  Folded,
+    separate-launch and oracle results must agree within the forward tolerance."""
+    from uspace_amd import _hip
+    from uspace_amd.tools.utils_uvit import get_nnet
+    torch.manual_seed(1234)
+    net = get_nnet("uvit", num_classes=-1, **COMMON, **S_CFG).cuda().eval()
+    with torch.no_grad():
+        net.pos_embed.mul_(50.0)
+        net.pos_embed.add_(3.0)
+        for i, blk in enumerate(net._blocks()):
+            blk.attn.proj.bias.fill_(0.75 * (1 + i % 3))
+            blk.mlp.fc2.bias.fill_(-0.5 * (1 + i % 2))
+            if hasattr(blk, "skip_linear"):
+                blk.skip_linear.bias.fill_(1.25)
+            blk.norm1.bias.normal_(0.0, 0.3)
+            blk.norm2.weight.normal_(1.0, 0.2)
+    z = _z(64)
+    L = _hip.lib()
+    outs = {}
+    try:
+        for fold in (1, 0):
+            _hip.check(L.uspace_uvit_set_ln_fold(fold), "set_ln_fold")
+            outs[fold], _ = net(z, _t(0.4, 64), None, edit_loc=None)
+    finally:
+        L.uspace_uvit_set_ln_fold(-1)
+    ref = _oracle_rows(net, S_CFG, z, 0.4, ROWS, edit_loc=None)
+    idx = torch.tensor(ROWS)
+    e_fold = rel_l2(outs[1][idx].cpu().numpy(), ref)
+    e_sep = rel_l2(outs[0][idx].cpu().numpy(), ref)
+    assert e_sep <= FWD_TOL and e_fold <= FWD_TOL, (e_fold, e_sep)
+    assert e_fold <= 1.5 * e_sep + 1e-3, (e_fold, e_sep)          # folding must not be the less accurate path
+    assert rel_l2(outs[1].cpu().numpy(), outs[0].cpu().numpy()) <= FWD_TOL
