@@ -43,9 +43,12 @@ __device__ __forceinline__ float wave_max(float v) {
 // erf-GELU (nn.GELU default, reference libs/timm.py:97).  erf by Abramowitz-Stegun 7.1.26
 // (|abs error| <= 1.5e-7, far below the bf16 rounding of the stored result): one v_rcp, one v_exp and
 // a handful of FMAs instead of libm's branchy erff (which cost ~16 us per 256x256 tile round in the fc1 epilogue).
-// With x = |v| / sqrt(2), t = 1 / (1 + p x), P(t) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))):
-//   gelu(v) = v/2 (1 + sign(v) erf(x)) = max(v, 0) - |v| (P(t) / 2) exp(-v^2 / 2)
-// (0.5 v + 0.5 |v| = max(v, 0); the 1/2 is folded into the coefficients, 1/sqrt(2) into p and the exponent).
+// With x = |v| / sqrt(2), t = 1 / (1 + p x), P(t) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))), w = P(t) exp(-x^2) / 2
+// (0 < w <= 1/2):
+//   gelu(v) = v/2 (1 + sign(v) erf(x)) = max(v, 0) - |v| w = max(v - v w, v w)
+// (v >= 0: v - v w >= v w because w <= 1/2; v < 0: v w > v - v w for the same reason) -- no sign handling at all, and every
+// operation except the |v| inside t works on packed pairs.  The 1/2 is folded into the coefficients, 1/sqrt(2) into p and
+// the exponent.
 #define US_GELU_P 0.23164189f            /* 0.3275911 / sqrt(2) */
 #define US_GELU_A1 0.127414796f
 #define US_GELU_A2 (-0.142248368f)
@@ -54,15 +57,14 @@ __device__ __forceinline__ float wave_max(float v) {
 #define US_GELU_A5 0.5307027145f
 #define US_GELU_E (-0.72134752044f)      /* -log2(e) / 2 */
 __device__ __forceinline__ float gelu_erf(float v) {
-    const float ax = fabsf(v);
-    const float t = __builtin_amdgcn_rcpf(fmaf(US_GELU_P, ax, 1.0f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(US_GELU_P, fabsf(v), 1.0f));
     const float e = __builtin_amdgcn_exp2f(v * v * US_GELU_E);
     float q = fmaf(US_GELU_A5, t, US_GELU_A4);
     q = fmaf(q, t, US_GELU_A3);
     q = fmaf(q, t, US_GELU_A2);
     q = fmaf(q, t, US_GELU_A1);
-    q *= t;
-    return fmaf(-ax, q * e, fmaxf(v, 0.0f));
+    const float m = v * (q * t * e);
+    return fmaxf(v - m, m);
 }
 // The same over NV x 4 values stage by stage: every stage is NV x 4 independent instructions, so the dependent chain of
 // one value (about a dozen operations of 4-8 cycles latency each) is covered by the others.  The one-value-at-a-time
@@ -77,12 +79,14 @@ template <int NV>
 __device__ __forceinline__ void gelu_erf_batch(f32x4 (&v)[NV]) {
     f32x4 t[NV], e[NV], q[NV];
 #pragma unroll
-    for (int j = 0; j < NV; ++j)
+    for (int j = 0; j < NV; ++j) {
+        // 1 + p |v|: one v_fma_f32 per value with the |.| source modifier (packed fp32 instructions have no abs; left to the
+        // compiler this becomes a v_and_b32 per value plus a packed fma per pair)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            t[j][c] = fmaf(US_GELU_P, fabsf(v[j][c]), 1.0f);
-            e[j][c] = v[j][c] * v[j][c] * US_GELU_E;
-        }
+        for (int c = 0; c < 4; ++c) asm("v_fma_f32 %0, |%1|, %2, 1.0" : "=v"(t[j][c]) : "v"(v[j][c]), "s"(US_GELU_P));
+        e[j] = v[j] * v[j];            // whole-vector forms: packed multiplies
+        e[j] = e[j] * US_GELU_E;
+    }
     US_STAGE_END(t)
     US_STAGE_END(e)
 #pragma unroll
@@ -96,34 +100,32 @@ __device__ __forceinline__ void gelu_erf_batch(f32x4 (&v)[NV]) {
         for (int c = 0; c < 4; ++c) e[j][c] = __builtin_amdgcn_exp2f(e[j][c]);
     US_STAGE_END(e)
 #pragma unroll
-    for (int j = 0; j < NV; ++j)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) q[j][c] = fmaf(US_GELU_A5, t[j][c], US_GELU_A4);
+    for (int j = 0; j < NV; ++j) q[j] = t[j] * US_GELU_A5 + US_GELU_A4;
     US_STAGE_END(q)
 #pragma unroll
-    for (int j = 0; j < NV; ++j)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) q[j][c] = fmaf(q[j][c], t[j][c], US_GELU_A3);
+    for (int j = 0; j < NV; ++j) q[j] = q[j] * t[j] + US_GELU_A3;
     US_STAGE_END(q)
 #pragma unroll
-    for (int j = 0; j < NV; ++j)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) q[j][c] = fmaf(q[j][c], t[j][c], US_GELU_A2);
+    for (int j = 0; j < NV; ++j) q[j] = q[j] * t[j] + US_GELU_A2;
     US_STAGE_END(q)
 #pragma unroll
-    for (int j = 0; j < NV; ++j)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) q[j][c] = fmaf(q[j][c], t[j][c], US_GELU_A1);
+    for (int j = 0; j < NV; ++j) q[j] = q[j] * t[j] + US_GELU_A1;
     US_STAGE_END(q)
 #pragma unroll
-    for (int j = 0; j < NV; ++j)
+    for (int j = 0; j < NV; ++j) t[j] = t[j] * e[j];
+    US_STAGE_END(t)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) q[j][c] = q[j][c] * t[j][c] * e[j][c];
+    for (int j = 0; j < NV; ++j) q[j] = q[j] * t[j];
     US_STAGE_END(q)
 #pragma unroll
-    for (int j = 0; j < NV; ++j)
+    for (int j = 0; j < NV; ++j) q[j] = v[j] * q[j];       // m = v w
+    US_STAGE_END(q)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[j][c] = fmaf(-fabsf(v[j][c]), q[j][c], fmaxf(v[j][c], 0.0f));
+    for (int j = 0; j < NV; ++j) {
+        t[j] = v[j] - q[j];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[j][c] = fmaxf(t[j][c], q[j][c]);
+    }
     US_STAGE_END(v)
 }
 #undef US_STAGE_END
