@@ -172,6 +172,18 @@ USPACE_API int uspace_add_broadcast_rows(float* x, uint16_t* x_bf16, const float
 USPACE_API int uspace_direction_accumulate(const float* feat, const int* attr, float* pos_sum, float* neg_sum,
                                            int B, long F, int A, uspace_stream_t stream);
 
+/* Principal directions of tapped activations (reference: tools/utils_pca.py:13-50 over sklearn PCA(svd_solver="full"),
+ * tools/utils_vis.py:80-118) from the N x N Gram matrix of the centred data; the F-sized contractions run on the fp64 matrix
+ * cores (products of fp32 data are exact in fp64), only the N x N symmetric eigen-decomposition is left to the caller.
+ *   center_cols : xc[N,F] = x[N,F] - column mean                         (F % 4 == 0; xc may alias x)
+ *   gram_f64    : G[N,N] (fp64, symmetric, fully written) = xc . xc^T     (F % 4 == 0)
+ *   project_rows: out[n,F] (fp32) = Ut[n,N] (fp64, row-major) . xc[N,F]
+ *   normalize_rows_signed: every row of v[n,F] to unit length with its largest-magnitude entry positive */
+USPACE_API int uspace_center_cols_f32(const float* x, float* xc, int N, long F, uspace_stream_t stream);
+USPACE_API int uspace_gram_f64(const float* x, double* G, int N, long F, uspace_stream_t stream);
+USPACE_API int uspace_project_rows_f64(const double* Ut, const float* x, float* out, int n, int N, long F, uspace_stream_t stream);
+USPACE_API int uspace_normalize_rows_signed(float* v, int n, long F, uspace_stream_t stream);
+
 /* fp32 -> bf16 (round to nearest even). */
 USPACE_API int uspace_cast_f32_bf16(const float* src, uint16_t* dst, long n, uspace_stream_t stream);
 

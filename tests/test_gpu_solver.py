@@ -300,3 +300,29 @@ def test_group_controlled_error_norm_on_the_device():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_pca_small_variance_components_survive_the_gram_matrix():
+    """Directions whose singular value is 1e-5 of the largest: an fp32 Gram matrix (eigenvalue ratio 1e-10, below fp32's 1e-7)
+    loses them; the fp64-matrix-core Gram of csrc/pca.hip keeps them.  Compared with the fp64-SVD oracle on the
+    same fp32 data, up to sign; odd feature count exercises the padding and the feature tail."""
+    from oracle import pca_oracle as PO
+    from uspace_amd.tools.utils_pca import pca_components
+    rng = np.random.default_rng(5)
+    for shape in ((4, 8, 8), (3, 7, 5)):
+        N, F = 48, int(np.prod(shape))
+        sv = np.array([10.0, 3.0, 1.0, 1e-2, 1e-4], np.float64)
+        u, _ = np.linalg.qr(rng.standard_normal((N, len(sv))))
+        v, _ = np.linalg.qr(rng.standard_normal((F, len(sv))))
+        x = ((u * sv) @ v.T + 0.5).astype(np.float32).reshape((N,) + shape)       # + a mean the centring must remove
+        want = PO.pca_components(x, len(sv))
+        got = pca_components(torch.from_numpy(x).cuda(), len(sv)).cpu().numpy()
+        assert got.shape == want.shape
+        for i in range(len(sv)):
+            a, b = got[i].ravel().astype(np.float64), want[i].ravel().astype(np.float64)
+            assert abs(np.linalg.norm(a) - 1.0) < 1e-5
+            cos = float(a @ b)
+            assert cos > 1.0 - 2e-3, (shape, i, cos)            # same direction AND same sign convention
+        # orthonormal set
+        gmat = got.reshape(len(sv), -1).astype(np.float64)
+        assert np.abs(gmat @ gmat.T - np.eye(len(sv))).max() < 1e-3

@@ -76,6 +76,10 @@ SIGNATURES = {
     "uspace_add_broadcast_rows": (_I, [_P, _P, _P, _F, _P, _I, _L, _P]),
     "uspace_cast_f32_bf16": (_I, [_P, _P, _L, _P]),
     "uspace_direction_accumulate": (_I, [_P, _P, _P, _P, _I, _L, _I, _P]),
+    "uspace_center_cols_f32": (_I, [_P, _P, _I, _L, _P]),
+    "uspace_gram_f64": (_I, [_P, _P, _I, _L, _P]),
+    "uspace_project_rows_f64": (_I, [_P, _P, _P, _I, _I, _L, _P]),
+    "uspace_normalize_rows_signed": (_I, [_P, _I, _L, _P]),
     "uspace_ode_combine": (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _L, _P]),
     "uspace_ode_error_norm": (_I, [_P, _P, ctypes.POINTER(_P), ctypes.POINTER(_F), _I, _F, _F, _L, _P, _P, _P]),
     "uspace_uvit_num_params": (_I, [ctypes.POINTER(UvitConfig)]),

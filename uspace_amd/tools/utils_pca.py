@@ -3,9 +3,11 @@ tools/utils_vis.py:62-118 -- faiss ``PCAMatrix`` / sklearn ``PCA(svd_solver="ful
 the read hook saved as ``{batch_id}_{t:.2f}.npy``; output ``pca{n}_{t}.npy`` of shape ``[n, C, W, H]``).
 
 The features stay on the device: N (a few thousand samples) is far below the feature size (4 096 for the latent,
-263 168 for the mid block), so the directions come from the N x N Gram matrix of the centred data -- one library GEMM
-and a symmetric eigen-decomposition -- instead of an SVD of the N x F matrix on the host.  Signs follow sklearn's
-convention (largest-magnitude entry of each direction positive); faiss' are arbitrary.
+263 168 for the mid block), so the directions come from the N x N Gram matrix of the centred data instead of an SVD of the
+N x F matrix on the host.  Centring, the Gram matrix (fp64 matrix cores: products of fp32 data are exact, so small trailing
+components are not drowned by the squared condition number of an fp32 Gram matrix), the projection U^T x and the
+normalisation are kernels of libuspace_hip.so (csrc/pca.hip); only the N x N symmetric eigen-decomposition is a library
+call.  Signs follow sklearn's convention (largest-magnitude entry of each direction positive); faiss' are arbitrary.
 """
 import os
 
@@ -29,16 +31,26 @@ def pca_components(feats, n_components):
     shape = tuple(feats.shape[1:])
     if not (0 < n_components <= min(N, int(np.prod(shape)))):
         raise ValueError(f"n_components={n_components} must be between 1 and min(n_samples, n_features)")
-    x = feats.detach().to(torch.float32).reshape(N, -1)
-    x = x - x.mean(dim=0, keepdim=True)
-    gram = (x @ x.t()).to(torch.float64)                 # [N, N]; its eigenvectors are the left singular vectors of x
-    evals, evecs = torch.linalg.eigh(gram)               # ascending
+    x = feats.detach().to(torch.float32).reshape(N, -1).contiguous()
+    F = x.shape[1]
+    pad = (-F) % 4                                       # the kernels read 16-byte feature groups
+    if pad:
+        x = torch.cat([x, x.new_zeros(N, pad)], dim=1)
+    Fp = F + pad
+    L, st = _hip.lib(), _hip.stream_ptr()
+    xc = torch.empty_like(x)
+    _hip.check(L.uspace_center_cols_f32(_hip.ptr(x), _hip.ptr(xc), N, Fp, st), "uspace_center_cols_f32")
+    gram = torch.empty(N, N, dtype=torch.float64, device=x.device)
+    _hip.check(L.uspace_gram_f64(_hip.ptr(xc), _hip.ptr(gram), N, Fp, st), "uspace_gram_f64")
+    evals, evecs = torch.linalg.eigh(gram)               # N x N, ascending: its eigenvectors are the left singular vectors of xc
     idx = torch.argsort(evals, descending=True)[:n_components]
-    u = evecs[:, idx].to(torch.float32)                  # [N, n]
-    comps = u.t() @ x                                    # sigma_i * v_i
-    comps = comps / comps.norm(dim=1, keepdim=True).clamp_min(1e-30)
-    big = comps.abs().argmax(dim=1)
-    comps = comps * torch.sign(comps[torch.arange(n_components, device=comps.device), big])[:, None]
+    ut = evecs[:, idx].t().contiguous()                  # [n, N] fp64
+    comps = torch.empty(n_components, Fp, dtype=torch.float32, device=x.device)
+    _hip.check(L.uspace_project_rows_f64(_hip.ptr(ut), _hip.ptr(xc), _hip.ptr(comps), n_components, N, Fp, st),
+               "uspace_project_rows_f64")                # sigma_i * v_i
+    _hip.check(L.uspace_normalize_rows_signed(_hip.ptr(comps), n_components, Fp, st), "uspace_normalize_rows_signed")
+    if pad:
+        comps = comps[:, :F].contiguous()
     return comps.reshape((n_components,) + shape)
 
 
