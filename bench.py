@@ -186,6 +186,8 @@ def main():
     else:
         from uspace_amd.flow_matching import CNF
     cnf = CNF(net)                                             # product defaults: hipGraph replay of plain evaluations
+    if os.environ.get("USPACE_BENCH_EAGER") == "1":            # profiling aid: rocprofv3's kernel trace crashes on graph replays
+        net.use_graph = False
     B = args.batch
     g = torch.Generator().manual_seed(7 + rank)
     z = torch.randn(B, 4, 32, 32, generator=g).to(dev)
@@ -243,12 +245,13 @@ def main():
         fc1_flags = _hip.EPI_BIAS | _hip.EPI_GELU | _hip.EPI_OUT_BF16 | (_hip.EPI_LN_IN if fold else 0)
         fc1_ms, fc1_n, peaks = 0.0, 0, None
         if rank == 0 and not args.no_extra:
+            was = net.use_graph
             net.use_graph = False
             _hip.prof_gemm_begin(fc1_flags, Hd, D, 8192)
             solve(args.solver)
             torch.cuda.synchronize()
             fc1_ms, fc1_n = _hip.prof_gemm_end()
-            net.use_graph = True
+            net.use_graph = was
             peaks = _hip.prof_peaks()
         if world > 1:
             dist.barrier()
@@ -296,7 +299,8 @@ def main():
             "config": {"workload": f"BASELINE configs[{args.config - 1}]: {args.model} (U-ViT D={D} depth={cfg['depth']} L={L}), "
                                    f"batch {B}/GPU, {args.solver}-{args.ode_steps} fixed steps"
                                    + (", mid-block u-space write hook (t <= 0.4)" if wl["hook"] else "")
-                                   + ", seeded random-init weights, latent->latent (VAE excluded), hipGraph replay per evaluation",
+                                   + ", seeded random-init weights, latent->latent (VAE excluded), "
+                                   + ("hipGraph replay per evaluation" if net.use_graph else "eager launches"),
                        "global_batch": B * world, "nfe_per_solve": nfe, "parallelism": f"batch-sharded x{world}"},
             "nfe": nfe,
             "median_ms_per_step": median_ms, "per_step_ms_rank0": per_solve_ms,
