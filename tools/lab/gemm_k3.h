@@ -21,6 +21,7 @@ struct Args {
     int T;        // blocks per set and workgroup
     int runs;     // workgroups per row panel (N = runs * 2 * T * 128)
     unsigned long long* trace;   // optional: [2 sets][512 steps] s_memtime stamps of workgroup 0 (after each step's barrier)
+    unsigned long long* fine;    // optional: [2 sets][8 steps][8 stamps] inside compute steps 32..39 of workgroup 0
 };
 
 constexpr int BK = 64, ROW_BYTES = 128;
@@ -157,13 +158,20 @@ __global__ __launch_bounds__(512) void kernel(const Args g) {
         asm volatile("" ::: "memory");
     };
     // one compute step on stage s & 1; w_next: this set computes at step s+1 too (same block)
+    const bool fine_on = g.fine != nullptr && blockIdx.x == 0 && ws == 0;
+    auto stamp = [&](int k) {
+        if (fine_on && s >= 32 && s < 40 && lane == 0) g.fine[(set * 8 + (s - 32)) * 8 + k] = __builtin_readcyclecounter();
+    };
     auto compute_step = [&](bool w_next) {
         const char* cur = smem + (s & 1) * STAGE_BYTES;
         const char* nxt = smem + ((s + 1) & 1) * STAGE_BYTES;
+        stamp(0);
         MMA(af0, wf0, 0, 0, 1)
         SB();
+        stamp(1);
         if (w_next) stage_w(wblk, kplus(1), (s + 1) & 1, set);
         pre_duty();
+        stamp(2);
         LOAD_A(af1, cur, 1, c_k0)
         SB();
         MMA(af0, wf0, 0, 1, HM)
@@ -183,8 +191,11 @@ __global__ __launch_bounds__(512) void kernel(const Args g) {
         SB();
         MMA(af1, wf1, 1, 0, HM / 2)
         SB();
+        stamp(3);
         __syncthreads();
+        stamp(4);
         post_duty();
+        stamp(5);
         if (w_next) {
             LOAD_A(af0, nxt, 0, c_k0)
             LOAD_W(wf0, nxt, c_k0)
@@ -192,6 +203,7 @@ __global__ __launch_bounds__(512) void kernel(const Args g) {
         SB();
         MMA(af1, wf1, 1, HM / 2, HM)
         SB();
+        stamp(6);
     };
     // a step without matrix work and without loads: raw barrier (nothing of this set is in flight that a barrier
     // would have to wait for); resume: the partner has staged this set's W block, fetch the first fragments

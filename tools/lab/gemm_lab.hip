@@ -62,6 +62,7 @@ static void launch_k2(const k2::Args& a) {
 }
 
 static unsigned long long* g_trace = nullptr;
+static unsigned long long* g_fine = nullptr;
 template <int FLAGS, int E, int PRIO = 0>
 static void launch_k3(const k2::Args& a, int T) {
     k3::Args g{};
@@ -70,6 +71,7 @@ static void launch_k3(const k2::Args& a, int T) {
     g.T = T;
     g.runs = a.N / (2 * T * 128);
     g.trace = g_trace;
+    g.fine = g_fine;
     hipLaunchKernelGGL((k3::kernel<FLAGS, E, PRIO>), dim3((a.M / 256) * g.runs), dim3(512), 0, 0, g);
 }
 
@@ -229,6 +231,25 @@ int main(int argc, char** argv) {
                     printf("\n      step durations (set Y): ");
                     for (int q = 1; q < S; ++q) printf("%llu ", ht[512 + q] - ht[512 + q - 1]);
                     printf("\n      total X %llu", ht[S - 1] - ht[0]);
+                    if (prio == 0 && E == 8) {
+                        unsigned long long* df;
+                        HCHECK(hipMalloc(&df, 128 * 8));
+                        HCHECK(hipMemset(df, 0, 128 * 8));
+                        g_fine = df;
+                        run3();
+                        HCHECK(hipDeviceSynchronize());
+                        g_fine = nullptr;
+                        std::vector<unsigned long long> hf(128);
+                        HCHECK(hipMemcpy(hf.data(), df, 128 * 8, hipMemcpyDeviceToHost));
+                        HCHECK(hipFree(df));
+                        printf("\n      inside compute steps 32..39 (both sets computing), cycles: [first MFMA row | W DMA issue | to barrier | barrier wait | A DMA issue | frag loads + last MFMAs]");
+                        for (int st = 0; st < 2; ++st)
+                            for (int q = 0; q < 8; ++q) {
+                                const unsigned long long* v = &hf[(st * 8 + q) * 8];
+                                printf("\n        set %c step %d: %5llu %5llu %5llu %5llu %5llu %5llu | total %5llu", st ? 'Y' : 'X', 32 + q, v[1] - v[0], v[2] - v[1], v[3] - v[2],
+                                       v[4] - v[3], v[5] - v[4], v[6] - v[5], v[6] - v[0]);
+                            }
+                    }
                 }
             }
         }
