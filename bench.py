@@ -202,12 +202,12 @@ def main():
         sk["solver"] = "adaptive" if kind == "dopri5" else "fixed"
         return sk
 
-    def solve(kind):
+    def solve(kind, gather=True):
         kw = dict(dissect_name="bench", edit_loc=None, solver_kwargs=solver_kwargs(kind))
         if hk:
             kw.update(hk)
         out = cnf.decode(z, cond, **kw) if t2i else cnf.decode(z, None, **kw)
-        return gather_batch(out, B * world)                   # the one collective of the sampling path
+        return gather_batch(out, B * world) if gather else out   # the one collective of the sampling path
 
     def fence():
         torch.cuda.synchronize()
@@ -248,7 +248,7 @@ def main():
             was = net.use_graph
             net.use_graph = False
             _hip.prof_gemm_begin(fc1_flags, Hd, D, 8192)
-            solve(args.solver)
+            solve(args.solver, gather=False)                  # rank 0 only: no collective in here
             torch.cuda.synchronize()
             fc1_ms, fc1_n = _hip.prof_gemm_end()
             net.use_graph = was

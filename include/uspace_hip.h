@@ -110,6 +110,10 @@ USPACE_API int uspace_gemm_part_slots(int M, int N);
 /* Which tile configuration uspace_gemm_bf16 uses for an [M, N] output (host-side planning, no GPU work):
  * 0 = 256x256 tiles, 1 = 192x256, 2 = 128x128, 3 = rows [0, *split_rows) as 256x256 and the rest as 128x128. */
 USPACE_API int uspace_gemm_tile_choice(int M, int N, int* split_rows);
+/* The whole plan (host-side, no GPU work): out[8] = {choice as above, split_rows, BM, BN, tile rows, tile columns, number of
+ * 16-row remainder strips (each owned by the workgroups of one tile row), workgroups per round of 256 CUs}.  For choice 3 the
+ * fields after split_rows describe the 256x256 launch over rows [0, split_rows). */
+USPACE_API int uspace_gemm_plan(int M, int N, int* out);
 
 /* Sum of row-shifted GEMMs:  acc[m, n] = sum_t A[m + row_shift[t], 0:K1] . W[n, t*K1:(t+1)*K1]  (+ epilogue
  * as above).  With rows = pixels of a zero-bordered NHWC map [B, H+2, W+2, C] and the 9 shifts

@@ -469,6 +469,36 @@ def test_gemm_tile_planning_on_headline_shapes():
     assert L.uspace_gemm_tile_choice(0, 64, None) < 0
 
 
+def test_gemm_plans_cover_the_rows_and_waste_little_of_a_round():
+    """uspace_gemm_plan over the row counts of every BASELINE configuration (B*L: 4*257, 32*257, 32*334, 64*257, 64*334) and
+    every output width of the two model sizes: the tile rows plus the 16-row strips cover M exactly, strips never outnumber
+    tile rows, and the launch fills its rounds of workgroups to at least 60 % (85 % on the headline shapes) -- except where
+    the whole problem is smaller than one round."""
+    from uspace_amd import _hip
+    L = _hip.lib()
+    out = (ctypes.c_int * 8)()
+    worst = {}
+    for M in (4 * 257, 32 * 257, 32 * 334, 64 * 257, 64 * 334):
+        for N in (512, 1024, 1536, 2048, 3072, 4096):
+            assert L.uspace_gemm_plan(M, N, out) == 0
+            choice, split, BM, BN, tm, tn, ns, per_round = list(out)
+            rows = split if choice == 3 else M
+            assert tm * BM + 16 * ns >= rows > (tm - 1) * BM + (16 * (ns - 1) if ns else 0)        # covers, no empty tile row / strip
+            assert 0 <= ns <= tm and tn == -(-N // BN)
+            if ns:
+                assert tm * BM < rows                                                               # strips only for a real remainder
+            wgs = tm * tn
+            rounds = -(-wgs // per_round)
+            fill = wgs / (rounds * per_round)
+            worst[(M, N)] = fill
+            if wgs >= per_round:
+                assert fill >= 0.60, (M, N, list(out), fill)
+    for N in (1024, 3072, 4096):
+        assert worst[(64 * 257, N)] >= 0.99                  # the headline shapes run in whole rounds (1 / 3 / 4)
+    assert L.uspace_gemm_plan(64 * 257, 4096, out) == 0 and list(out)[4:7] == [64, 16, 4]            # 64 tile rows, 4 strips
+    assert L.uspace_gemm_plan(0, 64, out) < 0
+
+
 def test_hookplan_scalar_and_row_scales():
     from uspace_amd.libs.dissection import HookPlan
     for s in (2, 0.5, np.float32(0.5), np.float64(0.5), np.int64(2), torch.tensor(0.5), np.array(0.5), np.linspace(0, 1, 3)[1]):

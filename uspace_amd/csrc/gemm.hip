@@ -825,6 +825,19 @@ extern "C" int uspace_gemm_tile_choice(int M, int N, int* split_rows) {
     return c;
 }
 
+extern "C" int uspace_gemm_plan(int M, int N, int* out) {
+    if (M <= 0 || N <= 0 || !out) return USPACE_ERR_ARG;
+    int m1 = 0;
+    const TileChoice tc = choose_tile(M, N, &m1);
+    const int BM = tc == TILE_MID ? 192 : (tc == TILE_SMALL ? 128 : 256), BN = tc == TILE_SMALL ? 128 : 256;
+    const int per_round = tc == TILE_SMALL ? 512 : 256;
+    const int rows = tc == TILE_SPLIT ? m1 : M;                 // split: the plan of the 256x256 part
+    const int tn = us_cdiv(N, BN);
+    const Plan p = plan_rows(rows, BM, tn, per_round);
+    out[0] = (int)tc; out[1] = m1; out[2] = BM; out[3] = BN; out[4] = p.tiles_m; out[5] = tn; out[6] = p.n_strip; out[7] = per_round;
+    return USPACE_OK;
+}
+
 extern "C" int uspace_gemm_bf16_ext(const uint16_t* A, int lda, const uint16_t* A2, int lda2, int K1,
                                     const uint16_t* W, int ldw, int M, int N, int K, int epi_flags,
                                     const float* bias, const float* resid_in, int ld_resid,
