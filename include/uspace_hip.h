@@ -108,7 +108,8 @@ USPACE_API int uspace_uvit_get_ln_fold(void);
 USPACE_API int uspace_gemm_part_slots(int M, int N);
 
 /* Which tile configuration uspace_gemm_bf16 uses for an [M, N] output (host-side planning, no GPU work):
- * 0 = 256x256 tiles, 1 = 192x256, 2 = 128x128, 3 = rows [0, *split_rows) as 256x256 and the rest as 128x128. */
+ * 0 = 256x256 tiles, 1 = 192x256, 2 = 128x128, 3 = rows [0, *split_rows) as 256x256 and the rest as 128x128,
+ * 4 = 256x128 (short row counts / narrow outputs: twice the workgroups of 256x256 at 3/4 of its staging traffic). */
 USPACE_API int uspace_gemm_tile_choice(int M, int N, int* split_rows);
 /* The whole plan (host-side, no GPU work): out[8] = {choice as above, split_rows, BM, BN, tile rows, tile columns, number of
  * 16-row remainder strips (each owned by the workgroups of one tile row), workgroups per round of 256 CUs}.  For choice 3 the

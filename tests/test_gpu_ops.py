@@ -313,6 +313,8 @@ def test_output_head_matches_oracle(hip, B, D, extras):
     (16448, 1536, 64, 1),         # 192x256 with extra strips (80 tile rows + 14-row strips)
     (64 * 334, 1024, 64, None),   # U-ViT-L T2I proj/fc2 shape: 192x256 or the 256x256 + 128x128 split
     (16448, 1024, 64, 0),         # the headline shape: 256x256 with extra strips
+    (32 * 257, 1024, 128, 4),     # config 5 rows: 256x128 tiles (32 x 8 = one round) with two extra strips
+    (8 * 257, 4096, 64, 4),       # 256x128, 8 x 32 tiles, one strip
 ])
 def test_gemm_tile_configurations_at_full_row_counts(hip, M, N, K, expect):
     """Every tile configuration the planner can pick at BASELINE row counts, with the fused proj/fc2 epilogue
@@ -341,6 +343,8 @@ def test_gemm_tile_configurations_at_full_row_counts(hip, M, N, K, expect):
 @pytest.mark.parametrize("M,D,Kp,N2", [
     (16448, 1024, 64, 1024),     # headline row count: 256x256 tiles with extra strips on both sides
     (16448, 1024, 64, 512),      # consumer on 128x128 tiles
+    (32 * 257, 1024, 64, 1024),  # config 5 rows: producer and consumer on 256x128 tiles (4 x 2 waves) with extra strips
+    (8 * 257, 1024, 64, 4096),   # consumer on 256x128 tiles with one strip
     (64 * 334, 512, 64, 1536),   # U-ViT-S T2I rows: producer on 192x256 tiles
     (515, 256, 128, 256),        # small everything, ragged rows
     (4100, 64, 64, 256),         # consumer with a single K tile (no barrier inside its K loop)

@@ -464,6 +464,8 @@ def test_gemm_tile_planning_on_headline_shapes():
         assert choice(64 * 257, N)[0] == 0
     assert choice(64 * 334, 512)[0] == 1            # U-ViT-S T2I: 224 tiles of 192x256 = one round instead of 1.3
     assert choice(4 * 257, 1536)[0] == 2 and choice(300, 64)[0] == 2 and choice(16448, 128)[0] == 2
+    # 256x128 tiles where 256x256 would leave CUs idle and 128x128 needs two workgroups per CU (config 5 rows, N = 1024)
+    assert choice(32 * 257, 1024)[0] == 4 and choice(8 * 257, 4096)[0] == 4 and choice(4 * 257, 4096)[0] == 4
     c, rows = choice(64 * 334, 1024)
     assert c in (1, 3) and (c != 3 or (0 < rows < 64 * 334 and rows % 256 == 0))
     assert L.uspace_gemm_tile_choice(0, 64, None) < 0

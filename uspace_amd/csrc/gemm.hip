@@ -52,12 +52,20 @@ struct GemmArgs {
 };
 
 constexpr int BK = 64;           // bf16 elements per K step (128 B per LDS row)
+#ifndef USPACE_TALL_COST
+#define USPACE_TALL_COST 0.60    // one round of 256x128 tiles in units of a round of 256x256 tiles (measured, r02_gemm_ablation.md)
+#endif
 constexpr int ROW_BYTES = 128;
 
 // wave row `wm` owns extra-strip sub-tiles [wm*XN, wm*XN+XN) of its TN weight fragments (select chain:
 // a dynamic register-array index would go to scratch)
 template <int WM, int XN, int TN>
 __device__ __forceinline__ bf16x8 pick_w(const bf16x8 (&wf)[TN], int wm, int j) {
+    if constexpr (WM == 4) {   // (a chain of three selects keeps the fragment arrays in scratch: two levels instead)
+        const bf16x8 a = wf[j], b = wf[XN + j], c = wf[2 * XN + j], d = wf[3 * XN + j];
+        const bf16x8 lo = (wm & 1) ? b : a, hi = (wm & 1) ? d : c;
+        return (wm & 2) ? hi : lo;
+    }
     bf16x8 r = wf[j];
 #pragma unroll
     for (int w = 1; w < WM; ++w) r = (wm == w) ? wf[w * XN + j] : r;
@@ -66,6 +74,11 @@ __device__ __forceinline__ bf16x8 pick_w(const bf16x8 (&wf)[TN], int wm, int j) 
 
 template <int WM, int XN, int TN>
 __device__ __forceinline__ f32x4 pick_b(const f32x4 (&b)[TN], int wm, int j) {
+    if constexpr (WM == 4) {
+        const f32x4 a = b[j], b1 = b[XN + j], c = b[2 * XN + j], d = b[3 * XN + j];
+        const f32x4 lo = (wm & 1) ? b1 : a, hi = (wm & 1) ? d : c;
+        return (wm & 2) ? hi : lo;
+    }
     f32x4 r = b[j];
 #pragma unroll
     for (int w = 1; w < WM; ++w) r = (wm == w) ? b[w * XN + j] : r;
@@ -716,12 +729,14 @@ inline GemmArgs row_slice(const GemmArgs& a, int m_lo, int m_hi) {
     return g;
 }
 
-enum TileChoice { TILE_BIG = 0, TILE_MID = 1, TILE_SMALL = 2, TILE_SPLIT = 3 };
+enum TileChoice { TILE_BIG = 0, TILE_MID = 1, TILE_SMALL = 2, TILE_SPLIT = 3, TILE_TALL = 4 };
 
-// Three tile configurations, chosen by a round-count cost model (unit: one round of 256x256 tiles):
-//   256x256, 8 waves, ~130 KiB LDS, 1 workgroup/CU           cost 1.00 per round of 256 tiles
-//   192x256, 8 waves, ~112 KiB LDS, 1 workgroup/CU           cost 0.80 (3/4 of the work, same fixed costs)
-//   128x128, 4 waves,  ~66 KiB LDS, 2 workgroups/CU          cost 0.55 per round of 512 tiles
+// Four tile configurations, chosen by a round-count cost model (unit: one round of 256x256 tiles):
+//   256x256, 8 waves (2x4), ~130 KiB LDS, 1 workgroup/CU     cost 1.00 per round of 256 tiles
+//   192x256, 8 waves (2x4), ~112 KiB LDS, 1 workgroup/CU     cost 0.80 (3/4 of the work, same fixed costs)
+//   256x128, 8 waves (4x2), ~100 KiB LDS, 1 workgroup/CU     cost USPACE_TALL_COST (half the work, 3/4 of the staging)
+//   128x128, 4 waves (2x2),  ~66 KiB LDS, 2 workgroups/CU    cost 0.68 per round of 512 tiles, 0.50 for <= 256 (one per CU)
+// (measured per round on the U-ViT-L shapes at 1 028 ... 16 448 rows, `profiles/r02_gemm_ablation.md` section 6)
 // plus the split form: whole rounds of 256x256 tiles and the remaining rows as one round of 128x128 tiles (rows
 // are independent, so it is two launches).  Extra-strip plans (plan_rows) cost one more 16-row MFMA tile per workgroup.
 // Examples: U-ViT-L B=64 (M=16448): every shape -> 256x256 in exactly 3 / 1 / 4 / 1 / 1 rounds;
@@ -735,11 +750,15 @@ TileChoice choose_tile(int M, int N, int* split_rows) {
     auto strip = [](const Plan& p, int bm) { return strip_factor(p, bm); };
     const Plan ps = plan_rows(a.M, 128, us_cdiv(a.N, 128), 512);
     const long st = (long)ps.tiles_m * us_cdiv(a.N, 128);
-    const double cost_small = ((double)(st / 512) * 0.55 + (st % 512 ? (st % 512 <= 256 ? 0.33 : 0.55) : 0.0)) * strip(ps, 128);
+    auto small_rounds = [](long tiles) { return (double)(tiles / 512) * 0.68 + (tiles % 512 ? (tiles % 512 <= 256 ? 0.50 : 0.68) : 0.0); };
+    const double cost_small = small_rounds(st) * strip(ps, 128);
     const Plan pb = plan_rows(a.M, 256, tn, 256);
     const double cost_big = a.M >= 256 ? us_cdiv(pb.tiles_m * tn, 256) * strip(pb, 256) : 1e30;
     const Plan pm = plan_rows(a.M, 192, tn, 256);
     const double cost_mid = us_cdiv(pm.tiles_m * tn, 256) * strip(pm, 192) * 0.80;
+    const int tn_tall = us_cdiv(a.N, 128);
+    const Plan pt = plan_rows(a.M, 256, tn_tall, 256);
+    const double cost_tall = a.M >= 256 ? us_cdiv(pt.tiles_m * tn_tall, 256) * strip(pt, 256) * USPACE_TALL_COST : 1e30;
     double cost_split = 1e30;
     int m1 = 0;
     const int full_rounds = (int)(big_tiles / 256);
@@ -749,12 +768,13 @@ TileChoice choose_tile(int M, int N, int* split_rows) {
         const int rest = a.M - m1;
         if (rest > 0 && tm_full * tn == full_rounds * 256) {
             const long small_tiles = (long)us_cdiv(rest, 128) * us_cdiv(a.N, 128);
-            if (small_tiles <= 512) cost_split = full_rounds + 0.55 * (double)us_cdiv((int)small_tiles, 512) + 0.06;
+            if (small_tiles <= 512) cost_split = full_rounds + small_rounds(small_tiles) + 0.06;
         }
     }
     // the 256x256 form is the measured one on the headline shapes: the others must beat it by a clear margin
-    const double best = std::min(std::min(cost_big * 0.93, cost_mid), std::min(cost_small, cost_split));
+    const double best = std::min(std::min(std::min(cost_big * 0.93, cost_mid), std::min(cost_small, cost_split)), cost_tall);
     if (best == cost_big * 0.93) return TILE_BIG;
+    if (best == cost_tall) return TILE_TALL;
     if (best == cost_split) {
         *split_rows = m1;
         return TILE_SPLIT;
@@ -770,6 +790,7 @@ int dispatch_tile(const GemmArgs& a, hipStream_t s) {
     switch (tc) {
         case TILE_BIG: return launch<256, 256, 2, 4, FLAGS>(a, s, 256);
         case TILE_MID: return launch<192, 256, 2, 4, FLAGS>(a, s, 256);
+        case TILE_TALL: return launch<256, 128, 4, 2, FLAGS>(a, s, 256);
         case TILE_SPLIT: {
             int rc = launch<256, 256, 2, 4, FLAGS>(row_slice(a, 0, m1), s, 256);
             if (rc != USPACE_OK) return rc;
@@ -814,7 +835,7 @@ extern "C" int uspace_gemm_part_slots(int M, int N) {
     if (M <= 0 || N <= 0) return USPACE_ERR_ARG;
     int m1 = 0;
     TileChoice tc = choose_tile(M, N, &m1);
-    return us_cdiv(N, tc == TILE_SMALL ? 128 : 256);     // producers never take the split form
+    return us_cdiv(N, (tc == TILE_SMALL || tc == TILE_TALL) ? 128 : 256);     // producers never take the split form
 }
 
 extern "C" int uspace_gemm_tile_choice(int M, int N, int* split_rows) {
@@ -829,7 +850,7 @@ extern "C" int uspace_gemm_plan(int M, int N, int* out) {
     if (M <= 0 || N <= 0 || !out) return USPACE_ERR_ARG;
     int m1 = 0;
     const TileChoice tc = choose_tile(M, N, &m1);
-    const int BM = tc == TILE_MID ? 192 : (tc == TILE_SMALL ? 128 : 256), BN = tc == TILE_SMALL ? 128 : 256;
+    const int BM = tc == TILE_MID ? 192 : (tc == TILE_SMALL ? 128 : 256), BN = (tc == TILE_SMALL || tc == TILE_TALL) ? 128 : 256;
     const int per_round = tc == TILE_SMALL ? 512 : 256;
     const int rows = tc == TILE_SPLIT ? m1 : M;                 // split: the plan of the 256x256 part
     const int tn = us_cdiv(N, BN);
