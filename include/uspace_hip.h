@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define USPACE_ABI_VERSION 4
+#define USPACE_ABI_VERSION 5
 
 #define USPACE_OK 0
 #define USPACE_ERR_ARG (-1)         /* bad pointer / size / unsupported shape */
@@ -87,7 +87,14 @@ typedef struct uspace_gemm_ext {
     float* c_out;           /* [M] or NULL */
     int norm_dim;           /* LayerNorm width (row length of the producer's output) */
     float eps;
+    /* optional (any epilogue without LN_IN / GELU): workspace for the K-split form of small launches -- few output tiles and
+     * a long K are cut into K ranges whose fp32 partial sums go here and are added in a fixed order by a second kernel.
+     * uspace_gemm_split_ws_bytes(M, N, K) is the size it needs (0: the launch is never split); NULL or too small = no split.
+     * Must not alias any operand; 16-byte aligned. */
+    void* split_ws;
+    size_t split_ws_bytes;
 } uspace_gemm_ext;
+USPACE_API size_t uspace_gemm_split_ws_bytes(int M, int N, int K);
 USPACE_API int uspace_gemm_bf16_ext(const uint16_t* A, int lda, const uint16_t* A2, int lda2, int K1,
                                     const uint16_t* W, int ldw, int M, int N, int K, int epi_flags,
                                     const float* bias, const float* resid_in, int ld_resid,

@@ -1,5 +1,5 @@
 // Interleaved A/B timing of two builds of libuspace_hip.so on the U-ViT GEMM shapes (run on the GPU box):
-//   tools/lab/_build/gemm_ab <libA.so> <libB.so> [M] [rounds] [reps]
+//   tools/lab/_build/gemm_ab <libA.so> <libB.so> [M] [rounds] [reps] [D]
 // Both libraries run the same launches alternately inside one process (box-to-box and thermal drift is larger than
 // the differences of interest); prints the median and minimum per variant and whether the outputs agree.
 #include <dlfcn.h>
@@ -65,7 +65,7 @@ int main(int argc, char** argv) {
     const int M = argc > 3 ? atoi(argv[3]) : 16448;
     const int rounds = argc > 4 ? atoi(argv[4]) : 7;
     const int reps = argc > 5 ? atoi(argv[5]) : 10;
-    const int D = 1024, Bsz = M / 257 > 0 ? M / 257 : 1;
+    const int D = argc > 6 ? atoi(argv[6]) : 1024, Bsz = M / 257 > 0 ? M / 257 : 1;
     constexpr int B_ = USPACE_EPI_BIAS, G_ = USPACE_EPI_GELU, R_ = USPACE_EPI_RESIDUAL, F_ = USPACE_EPI_OUT_F32, H_ = USPACE_EPI_OUT_BF16, C_ = USPACE_EPI_CEN_OUT,
                   L_ = USPACE_EPI_LN_IN;
     std::mt19937 rng(99);
@@ -85,7 +85,8 @@ int main(int argc, char** argv) {
         }
     }
     uint16_t *dA, *dA2, *dW, *dO[2], *dCen[2];
-    float *db, *dR, *dF[2], *dPin, *dPout[2], *dC, *dCout[2], *dCs;
+    float *db, *dR, *dF[2], *dPin, *dPout[2], *dC, *dCout[2], *dCs, *dWs;
+    const size_t ws_bytes = (size_t)8 * M * D * 4;   // K-split workspace (ignored by libraries older than ABI 5)
     HCHECK(hipMalloc(&dA, nA * 2));
     HCHECK(hipMalloc(&dA2, (size_t)M * D * 2));
     HCHECK(hipMalloc(&dW, nW * 2));
@@ -94,6 +95,7 @@ int main(int argc, char** argv) {
     HCHECK(hipMalloc(&dR, hr.size() * 4));
     HCHECK(hipMalloc(&dPin, hpart.size() * 4));
     HCHECK(hipMalloc(&dC, M * 4));
+    HCHECK(hipMalloc(&dWs, ws_bytes));
     for (int v = 0; v < 2; ++v) {
         HCHECK(hipMalloc(&dO[v], (size_t)M * 4 * D * 2));
         HCHECK(hipMalloc(&dCen[v], (size_t)M * D * 2));
@@ -130,20 +132,22 @@ int main(int argc, char** argv) {
     for (const Shape& s : shapes) {
         auto run = [&](int v) {
             if (s.N == 0) {
-                const int rc = L[v].attn(dA, nullptr, dO[v], Bsz, 257, 16, nullptr);
+                const int rc = L[v].attn(dA, nullptr, dO[v], Bsz, 257, D / 64, nullptr);
                 if (rc) { fprintf(stderr, "attention rc %d\n", rc); exit(1); }
                 return;
             }
             uspace_gemm_ext ext{};
             ext.norm_dim = D;
             ext.eps = 1e-5f;
+            ext.split_ws = dWs;
+            ext.split_ws_bytes = ws_bytes;
             if (s.flags & C_) { ext.row_c = dC; ext.out_cen = dCen[v]; ext.ld_cen = D; ext.part_out = dPout[v]; }
             if (s.flags & L_) { ext.part_in = dPin; ext.np_in = 4; ext.colsum = dCs; ext.row_c = dC; ext.c_out = dCout[v]; }
             const bool skip = s.K == 2 * D;
             // resid_in read from dR, result to dF[v]: repeated launches are idempotent
             const int rc = L[v].gemm(dA, skip ? D : s.K, skip ? dA2 : nullptr, skip ? D : 0, skip ? D : s.K, dW, s.K, M, s.N, s.K, s.flags, db,
                                      (s.flags & R_) ? dR : nullptr, D, (s.flags & F_) ? dF[v] : nullptr, D, (s.flags & H_) ? dO[v] : nullptr, s.N,
-                                     (s.flags & (C_ | L_)) ? &ext : nullptr, nullptr);
+                                     &ext, nullptr);
             if (rc) { fprintf(stderr, "%s rc %d\n", s.name, rc); exit(1); }
         };
         for (int v = 0; v < 2; ++v) run(v);

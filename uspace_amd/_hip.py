@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libuspace_hip.so")
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_OUT_BF16 = 1, 2, 4, 8, 16
 EPI_CEN_OUT, EPI_LN_IN = 32, 64          # uspace_gemm_bf16_ext only (LayerNorm folded through the GEMMs)
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _ERR = {-1: "USPACE_ERR_ARG", -2: "USPACE_ERR_LAUNCH", -3: "USPACE_ERR_WORKSPACE"}
 
@@ -50,7 +50,8 @@ class ClipConfig(ctypes.Structure):
 class GemmExt(ctypes.Structure):
     _fields_ = [("row_c", ctypes.c_void_p), ("out_cen", ctypes.c_void_p), ("ld_cen", ctypes.c_int),
                 ("part_out", ctypes.c_void_p), ("part_in", ctypes.c_void_p), ("np_in", ctypes.c_int),
-                ("colsum", ctypes.c_void_p), ("c_out", ctypes.c_void_p), ("norm_dim", ctypes.c_int), ("eps", ctypes.c_float)]
+                ("colsum", ctypes.c_void_p), ("c_out", ctypes.c_void_p), ("norm_dim", ctypes.c_int), ("eps", ctypes.c_float),
+                ("split_ws", ctypes.c_void_p), ("split_ws_bytes", ctypes.c_size_t)]
 
 
 _P, _I, _L, _F, _SZ = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
@@ -62,6 +63,7 @@ SIGNATURES = {
     "uspace_gemm_bf16_ext": (_I, [_P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I,
                                   ctypes.POINTER(GemmExt), _P]),
     "uspace_gemm_part_slots": (_I, [_I, _I]),
+    "uspace_gemm_split_ws_bytes": (_SZ, [_I, _I, _I]),
     "uspace_fold_layernorm": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "uspace_center_rows": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "uspace_uvit_set_ln_fold": (_I, [_I]),
@@ -165,8 +167,9 @@ def require_device(t, name="tensor"):
 # ------------------------------------------------------------------------------------------
 # thin operator wrappers (used by the parity tests and by the solver); tensors are torch CUDA
 # ------------------------------------------------------------------------------------------
-def gemm(A, W, *, A2=None, bias=None, resid=None, gelu=False, out_f32=None, out_bf16=None):
-    """acc = [A|A2] @ W^T with fused epilogue; A/A2/W are torch.bfloat16, returns (out_f32, out_bf16)."""
+def gemm(A, W, *, A2=None, bias=None, resid=None, gelu=False, out_f32=None, out_bf16=None, split_ws=None):
+    """acc = [A|A2] @ W^T with fused epilogue; A/A2/W are torch.bfloat16, returns (out_f32, out_bf16).  split_ws: an optional
+    fp32 workspace tensor (uspace_gemm_split_ws_bytes) that allows the K-split form of small launches."""
     require_device(A, "A")
     M, K1 = A.shape
     N, K = W.shape
@@ -182,11 +185,18 @@ def gemm(A, W, *, A2=None, bias=None, resid=None, gelu=False, out_f32=None, out_
         flags |= EPI_OUT_F32
     if out_bf16 is not None:
         flags |= EPI_OUT_BF16
-    rc = lib().uspace_gemm_bf16(
-        ptr(A), A.stride(0), ptr(A2), A2.stride(0) if A2 is not None else 0, K1, ptr(W), W.stride(0), M, N, K, flags,
-        ptr(bias), ptr(resid), resid.stride(0) if resid is not None else 0,
-        ptr(out_f32), out_f32.stride(0) if out_f32 is not None else 0,
-        ptr(out_bf16), out_bf16.stride(0) if out_bf16 is not None else 0, stream_ptr())
+    args = (ptr(A), A.stride(0), ptr(A2), A2.stride(0) if A2 is not None else 0, K1, ptr(W), W.stride(0), M, N, K, flags,
+            ptr(bias), ptr(resid), resid.stride(0) if resid is not None else 0,
+            ptr(out_f32), out_f32.stride(0) if out_f32 is not None else 0,
+            ptr(out_bf16), out_bf16.stride(0) if out_bf16 is not None else 0)
+    if split_ws is not None:
+        require_device(split_ws, "split_ws")
+        ext = GemmExt()
+        ext.split_ws = ptr(split_ws).value
+        ext.split_ws_bytes = split_ws.numel() * split_ws.element_size()
+        rc = lib().uspace_gemm_bf16_ext(*args, ctypes.byref(ext), stream_ptr())
+    else:
+        rc = lib().uspace_gemm_bf16(*args, stream_ptr())
     check(rc, "uspace_gemm_bf16")
     return out_f32, out_bf16
 

@@ -49,6 +49,12 @@ struct GemmArgs {
     int ld_cen, np_in;
     float inv_d, eps;
     int wide;   // bf16 outputs (out_bf16, out_cen) allow 16-byte stores: row strides % 8 == 0, bases 16-byte aligned
+    // ring form (NST > 2): K tiles per workgroup (gridDim.y K-splits of nk_split tiles each; split s writes its raw fp32
+    // partial sums to out_f32 + s * split_stride)
+    int nk_split;
+    long split_stride;
+    float* split_ws;          // host side only: workspace for the K-split form (NULL: never split)
+    size_t split_ws_bytes;
 };
 
 constexpr int BK = 64;           // bf16 elements per K step (128 B per LDS row)
@@ -113,7 +119,12 @@ __device__ __forceinline__ int lds_off(int r, int c) { return r * ROW_BYTES + ((
 // at the scheduling barriers of the K loop).  Round 1 gave every workgroup ceil(64/64) = 1 row, i.e. 15/16 of an MFMA
 // tile wasted in each of them: +6 % matrix work everywhere.
 // ------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int FLAGS, bool XTRA>
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int WM, int WN, int FLAGS, bool XTRA, int NST = 2>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr int TM = BM / WM / 16;            // 16-row activation sub-tiles per wave
@@ -129,6 +140,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     constexpr int STAGE_BYTES = TILE_A_BYTES + TILE_W_BYTES + TILE_X_BYTES;
     static_assert(BM % ROWS_PER_ISSUE == 0 && BN % ROWS_PER_ISSUE == 0, "tile/threads mismatch");
     static_assert(TM % 2 == 0 && TN % WM == 0 && (WM == 2 || WM == 4), "wave tile shape");
+    static_assert(NST == 2 || !XTRA, "the ring form has no extra strips");
+    constexpr int IPT = ISSUES_A + ISSUES_W;    // LDS-DMA instructions per wave and K tile
+    static_assert((NST - 1) * IPT < 64, "vmcnt is a 6-bit counter");
 
     // LayerNorm folding: per-row values of this tile (main rows, then the 16 strip rows) are fetched at kernel start
     // (their latency sits under the first tile) and parked behind the stage buffers: consumer (d, rstd), producer
@@ -137,8 +151,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     // in-flight LDS-DMA (measured: fc1 +28 us), which undoes the load / compute overlap the loop is built on.
     constexpr bool ROWV = (FLAGS & (USPACE_EPI_LN_IN | USPACE_EPI_CEN_OUT)) != 0;
     constexpr int ROWV_BYTES = ROWV ? (BM + 16) * 8 : 0;
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES + ROWV_BYTES];
-    const uint32_t rowv_lds = (uint32_t)(uintptr_t)(US_LDS char*)(smem + 2 * STAGE_BYTES);
+    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE_BYTES + ROWV_BYTES];
+    const uint32_t rowv_lds = (uint32_t)(uintptr_t)(US_LDS char*)(smem + NST * STAGE_BYTES);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -224,8 +238,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
         const bf16_t* b = (gA2 && sl > 0) ? gA2 : gA;
         return (const char*)(b + (long)g.slab_shift[sl] * lda_l + kin);
     };
+    const int kt0 = NST > 2 ? (int)blockIdx.y * g.nk_split : 0;   // ring form: this workgroup's K range starts here
+    float* const out_f32 = NST > 2 ? g.out_f32 + (size_t)blockIdx.y * g.split_stride : g.out_f32;
     auto stage_a = [&](int kt, int buf) {
-        const int k0 = kt * BK;
+        const int k0 = (kt + kt0) * BK;
         char* base = smem + buf * STAGE_BYTES;
         const char* abase = a_base(k0);
 #pragma unroll
@@ -242,7 +258,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
         }
     };
     auto stage_w = [&](int kt, int buf) {
-        const char* wbase = (const char*)(gW + kt * BK);
+        const char* wbase = (const char*)(gW + (kt + kt0) * BK);
         char* base = smem + buf * STAGE_BYTES + TILE_A_BYTES;
 #pragma unroll
         for (int i = 0; i < ISSUES_W; ++i) {
@@ -318,16 +334,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
             xacc[j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pick_w<WM, XN>(wf, wm, j_), xf, xacc[j_], 0, 0, 0); \
     }
 
-    const int nk = g.K / BK;
-    stage_a(0, 0);
-    stage_w(0, 0);
-    if (nk > 1) stage_a(1, 1);
+    const int nk = NST > 2 ? g.nk_split : g.K / BK;
     // LayerNorm folding: thread t fetches the per-row values of tile row t (main rows, then the 16 strip rows) right
     // behind the first LDS-DMA stages -- their latency overlaps the first tile's -- and parks them in LDS after the barrier
+    // (ring form: before the stages, so that the counted wait for the first tile covers them)
     float2 pr[ROWV ? 8 : 1];
     float rc_v = 0.f;
     int rv_m = -1;
-    if constexpr (ROWV) {
+    auto fetch_rowv = [&]() {
         static_assert(BM + 16 <= THREADS || !ROWV, "one thread per tile row");
         const int t = tid;
         if (t < BM + (XTRA ? 16 : 0)) {
@@ -346,8 +360,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
                 }
             }
         }
+    };
+    if constexpr (NST > 2) {
+        // ring of NST stages, all filled up front (the host guarantees nk >= NST); the first tile is waited for by count
+        if constexpr (ROWV) fetch_rowv();
+#pragma unroll
+        for (int t = 0; t < NST; ++t) {
+            stage_a(t, t);
+            stage_w(t, t);
+        }
+        wait_vm<(NST - 1) * IPT>();
+        __builtin_amdgcn_s_barrier();
+    } else {
+        stage_a(0, 0);
+        stage_w(0, 0);
+        if (nk > 1) stage_a(1, 1);
+        if constexpr (ROWV) fetch_rowv();
+        __syncthreads();
     }
-    __syncthreads();
     if constexpr (ROWV) {
         if (tid < BM + 16) {
             float2 v = make_float2(0.f, 1.f);
@@ -424,13 +454,69 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
         if (MORE && MORE2 && late) stage_a(kt + 2, kt & 1);                                        \
         __builtin_amdgcn_sched_barrier(0);                                                         \
     }
-    // steady state is branch-free; the last two K tiles are peeled (no further prefetch / barrier)
-    {
+    // Ring form (small launches, one workgroup per CU: nothing else hides the L2 / HBM latency): same phases, but the
+    // barrier of tile kt waits by count for tile kt+1 only (NST-2 younger tiles stay in flight) and is followed by the
+    // refill of the buffer just freed with tile kt+NST -- both operands NST-1 tiles ahead instead of W less than one
+#define KTILE_R(kt, buf, nbuf, MORE, REFILL, WAITN)                                                \
+    {                                                                                              \
+        const char* cur = smem + (buf) * STAGE_BYTES;                                              \
+        MMA(af0, wf0, 0, 0, 1)                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        LOAD_A(af1, cur, 1, c_k0)                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        MMA(af0, wf0, 0, 1, HM)                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        MMA(af1, wf0, 1, 0, 1)                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        LOAD_A(af0, cur, 0, c_k1)                                                                  \
+        LOAD_W(wf1, cur, c_k1)                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        MMA(af1, wf0, 1, 1, HM)                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        MMA(af0, wf1, 0, 0, 1)                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        LOAD_A(af1, cur, 1, c_k1)                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        MMA(af0, wf1, 0, 1, HM)                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        MMA(af1, wf1, 1, 0, HM / 2)                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (MORE) {                                                                                \
+            wait_vm<WAITN>();                                                                      \
+            __builtin_amdgcn_s_barrier(); /* tile kt+1 landed for everyone; buffer buf is free */  \
+            if (REFILL) {                                                                          \
+                stage_a(kt + NST, buf);                                                            \
+                stage_w(kt + NST, buf);                                                            \
+            }                                                                                      \
+            const char* nxt = smem + (nbuf) * STAGE_BYTES;                                         \
+            LOAD_A(af0, nxt, 0, c_k0)                                                              \
+            LOAD_W(wf0, nxt, c_k0)                                                                 \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        MMA(af1, wf1, 1, HM / 2, HM)                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    }
+    if constexpr (NST > 2) {
+        int kt = 0, buf = 0;
+        for (; kt + NST < nk; ++kt) {
+            const int nb = buf + 1 == NST ? 0 : buf + 1;
+            KTILE_R(kt, buf, nb, true, true, (NST - 2) * IPT)
+            buf = nb;
+        }
+        for (; kt + 1 < nk; ++kt) {       // the last NST-1 barriers: nothing left to refill, wait for everything in flight
+            const int nb = buf + 1 == NST ? 0 : buf + 1;
+            KTILE_R(kt, buf, nb, true, false, 0)
+            buf = nb;
+        }
+        KTILE_R(kt, buf, 0, false, false, 0)
+    } else {
+        // steady state is branch-free; the last two K tiles are peeled (no further prefetch / barrier)
         int kt = 0;
         for (; kt + 2 < nk; ++kt) KTILE(kt, true, true)
         if (kt + 1 < nk) { KTILE(kt, true, false) ++kt; }
         KTILE(kt, false, false)
     }
+#undef KTILE_R
 #undef KTILE
 #undef LOAD_A
 #undef LOAD_W
@@ -472,7 +558,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
         return;
 #endif
         if constexpr (FLAGS & USPACE_EPI_OUT_F32) {
-            *(f32x4*)(g.out_f32 + (size_t)m * g.ld_f32 + n) = v;
+            *(f32x4*)(out_f32 + (size_t)m * g.ld_f32 + n) = v;
         }
         if constexpr (FLAGS & USPACE_EPI_OUT_BF16) {
             uint2 p;
@@ -568,7 +654,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
             uint2 pk[TN], pc[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                if constexpr (FLAGS & USPACE_EPI_OUT_F32) *(f32x4*)(g.out_f32 + (size_t)m * g.ld_f32 + n0 + wn * (BN / WN) + j * 16 + fq * 4) = v[j];
+                if constexpr (FLAGS & USPACE_EPI_OUT_F32) *(f32x4*)(out_f32 + (size_t)m * g.ld_f32 + n0 + wn * (BN / WN) + j * 16 + fq * 4) = v[j];
                 if constexpr (FLAGS & USPACE_EPI_OUT_BF16) {
                     pk[j].x = pack_bf2(v[j][0], v[j][1]);
                     pk[j].y = pack_bf2(v[j][2], v[j][3]);
@@ -711,6 +797,100 @@ int launch(const GemmArgs& a, hipStream_t s, int wg_per_round) {
     return USPACE_OK;
 }
 
+// ---- small launches: 128x128 tiles, one workgroup per CU, ring of 4 LDS stages, optional split along K.
+// With at most one workgroup per CU nothing but the workgroup's own prefetch depth hides the L2 / HBM latency: the
+// two-stage loop above spends ~2 000 cycles per K tile there (512 of them MFMA).  Long K with few tiles (fc2 / skip_linear
+// of a small batch: 36 tiles x 32 K tiles for U-ViT-S at 4 x 257 rows) is cut into S K-ranges (gridDim.y), each writing raw
+// fp32 partial sums to a caller-provided workspace; splitk_finish_kernel adds them in a fixed order and applies the epilogue.
+constexpr int RING_NST = 4;
+constexpr int RING_MAX_WG = 256;          // one workgroup per CU (128 KiB of LDS each)
+
+// largest S in {8, 4, 2} with tiles * S <= 256 workgroups and whole K ranges of at least 512 (below that the second
+// kernel costs more than the shorter K loop saves)
+inline int split_factor(int tiles, int K) {
+    const int nk = K / BK;
+    for (int S = 8; S >= 2; S >>= 1)
+        if (tiles * S <= RING_MAX_WG && nk % S == 0 && nk / S >= RING_NST && K / S >= 512) return S;
+    return 1;
+}
+
+inline bool ring_ok(int M, int N, int K) {
+    return (long)us_cdiv(M, 128) * us_cdiv(N, 128) <= RING_MAX_WG && K / BK >= RING_NST;
+}
+
+template <int FLAGS>
+int launch_ring(const GemmArgs& a, hipStream_t s, int S, float* ws) {
+    GemmArgs g = a;
+    g.tiles_n = us_cdiv(g.N, 128);
+    g.tiles_m = us_cdiv(g.M, 128);
+    g.m_main = g.M;
+    g.n_strip = 0;
+    g.nk_split = g.K / BK / S;
+    g.split_stride = 0;
+    if (S > 1) {
+        g.out_f32 = ws;
+        g.ld_f32 = g.N;
+        g.split_stride = (long)g.M * g.N;
+    }
+    const bool rec = g_rec.on && g_rec.flags == FLAGS && g_rec.N == g.N && g_rec.K == g.K && g_rec.used + 2 <= g_rec.cap;
+    if (rec) (void)hipEventRecord(g_rec.ev[g_rec.used], s);
+    hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2, FLAGS, false, RING_NST>), dim3(g.tiles_m * g.tiles_n, S), dim3(256), 0, s, g);
+    if (rec) {
+        (void)hipEventRecord(g_rec.ev[g_rec.used + 1], s);
+        g_rec.used += 2;
+    }
+    US_CHECK_LAUNCH();
+    return USPACE_OK;
+}
+
+// One workgroup per row: v = sum_s ws[s][m][:] (+ bias) (+ residual), then the outputs of the fused epilogue.  A producer
+// (CEN_OUT) puts the row's partial sums into slot 0 of its part_out row and zeroes the other slots (consumers add them all).
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* ws, int S, long stride, GemmArgs g, int flags, int slots) {
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const float rc = (flags & USPACE_EPI_CEN_OUT) ? g.row_c[m] : 0.f;
+    float ps1 = 0.f, ps2 = 0.f;
+    for (int n = tid * 4; n < g.N; n += 256 * 4) {
+        f32x4 v = *(const f32x4*)(ws + (size_t)m * g.N + n);
+        for (int sp = 1; sp < S; ++sp) v += *(const f32x4*)(ws + sp * stride + (size_t)m * g.N + n);
+        if (flags & USPACE_EPI_RESIDUAL) v += *(const f32x4*)(g.resid + (size_t)m * g.ld_resid + n);
+        if (flags & USPACE_EPI_BIAS) v += *(const f32x4*)(g.bias + n);
+        if (flags & USPACE_EPI_OUT_F32) *(f32x4*)(g.out_f32 + (size_t)m * g.ld_f32 + n) = v;
+        if (flags & USPACE_EPI_OUT_BF16) {
+            uint2 p;
+            p.x = pack_bf2(v[0], v[1]);
+            p.y = pack_bf2(v[2], v[3]);
+            *(uint2*)(g.out_bf16 + (size_t)m * g.ld_bf16 + n) = p;
+        }
+        if (flags & USPACE_EPI_CEN_OUT) {
+            const f32x4 vc = v - rc;
+            ps1 += (vc[0] + vc[1]) + (vc[2] + vc[3]);
+            ps2 += (vc[0] * vc[0] + vc[1] * vc[1]) + (vc[2] * vc[2] + vc[3] * vc[3]);
+            uint2 p;
+            p.x = pack_bf2(vc[0], vc[1]);
+            p.y = pack_bf2(vc[2], vc[3]);
+            *(uint2*)(g.out_cen + (size_t)m * g.ld_cen + n) = p;
+        }
+    }
+    if (flags & USPACE_EPI_CEN_OUT) {
+        __shared__ float red[4][2];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            ps1 += __shfl_xor(ps1, o, 64);
+            ps2 += __shfl_xor(ps2, o, 64);
+        }
+        if ((tid & 63) == 0) {
+            red[tid >> 6][0] = ps1;
+            red[tid >> 6][1] = ps2;
+        }
+        __syncthreads();
+        if (tid < slots) {
+            float2 o = make_float2(0.f, 0.f);
+            if (tid == 0) o = make_float2((red[0][0] + red[1][0]) + (red[2][0] + red[3][0]), (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]));
+            *(float2*)(g.part_out + ((size_t)m * slots + tid) * 2) = o;
+        }
+    }
+}
+
 // Rows are independent, so one GEMM may be issued as two launches over disjoint row ranges.
 inline GemmArgs row_slice(const GemmArgs& a, int m_lo, int m_hi) {
     GemmArgs g = a;
@@ -787,6 +967,19 @@ int dispatch_tile(const GemmArgs& a, hipStream_t s) {
     int m1 = 0;
     TileChoice tc = choose_tile(a.M, a.N, &m1);
     if (tc == TILE_SPLIT && (FLAGS & USPACE_EPI_CEN_OUT)) tc = TILE_BIG;   // one partial-sum stride per launch
+    if (tc == TILE_SMALL && ring_ok(a.M, a.N, a.K)) {
+        constexpr bool SPLITTABLE = (FLAGS & (USPACE_EPI_LN_IN | USPACE_EPI_GELU)) == 0;
+        const int tiles = us_cdiv(a.M, 128) * us_cdiv(a.N, 128);
+        const int S = (SPLITTABLE && a.split_ws) ? split_factor(tiles, a.K) : 1;
+        if (S > 1 && (size_t)S * a.M * a.N * 4 <= a.split_ws_bytes) {
+            int rc = launch_ring<USPACE_EPI_OUT_F32>(a, s, S, a.split_ws);
+            if (rc != USPACE_OK) return rc;
+            hipLaunchKernelGGL(splitk_finish_kernel, dim3(a.M), dim3(256), 0, s, a.split_ws, S, (long)a.M * a.N, a, FLAGS, us_cdiv(a.N, 128));
+            US_CHECK_LAUNCH();
+            return USPACE_OK;
+        }
+        return launch_ring<FLAGS>(a, s, 1, nullptr);
+    }
     switch (tc) {
         case TILE_BIG: return launch<256, 256, 2, 4, FLAGS>(a, s, 256);
         case TILE_MID: return launch<192, 256, 2, 4, FLAGS>(a, s, 256);
@@ -836,6 +1029,14 @@ extern "C" int uspace_gemm_part_slots(int M, int N) {
     int m1 = 0;
     TileChoice tc = choose_tile(M, N, &m1);
     return us_cdiv(N, (tc == TILE_SMALL || tc == TILE_TALL) ? 128 : 256);     // producers never take the split form
+}
+
+extern "C" size_t uspace_gemm_split_ws_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % BK) return 0;
+    int m1 = 0;
+    if (choose_tile(M, N, &m1) != TILE_SMALL || !ring_ok(M, N, K)) return 0;
+    const int S = split_factor(us_cdiv(M, 128) * us_cdiv(N, 128), K);
+    return S > 1 ? (size_t)S * M * N * 4 : 0;
 }
 
 extern "C" int uspace_gemm_tile_choice(int M, int N, int* split_rows) {
@@ -891,7 +1092,10 @@ extern "C" int uspace_gemm_bf16_ext(const uint16_t* A, int lda, const uint16_t* 
     g.row_c = nullptr; g.out_cen = nullptr; g.part_out = nullptr; g.part_in = nullptr; g.colsum = nullptr; g.c_out = nullptr;
     g.ld_cen = 0; g.np_in = 0; g.inv_d = 0.f; g.eps = 0.f;
     g.wide = 0;
+    g.nk_split = 0; g.split_stride = 0; g.split_ws = nullptr; g.split_ws_bytes = 0;
     if (ext) {
+        g.split_ws = (float*)ext->split_ws; g.split_ws_bytes = ext->split_ws_bytes;
+        if (g.split_ws && ((uintptr_t)g.split_ws & 15)) return USPACE_ERR_ARG;
         g.row_c = ext->row_c; g.out_cen = ext->out_cen; g.ld_cen = ext->ld_cen; g.part_out = ext->part_out;
         g.part_in = ext->part_in; g.np_in = ext->np_in; g.colsum = ext->colsum; g.c_out = ext->c_out;
         g.inv_d = ext->norm_dim > 0 ? 1.0f / (float)ext->norm_dim : 0.f;
@@ -945,6 +1149,7 @@ extern "C" int uspace_gemm_slabs_bf16(const uint16_t* A, int lda, const uint16_t
     g.row_c = nullptr; g.out_cen = nullptr; g.part_out = nullptr; g.part_in = nullptr; g.colsum = nullptr; g.c_out = nullptr;
     g.ld_cen = 0; g.np_in = 0; g.inv_d = 0.f; g.eps = 0.f;
     if (epi_flags & (USPACE_EPI_CEN_OUT | USPACE_EPI_LN_IN)) return USPACE_ERR_ARG;
+    g.nk_split = 0; g.split_stride = 0; g.split_ws = nullptr; g.split_ws_bytes = 0;
     g.wide = wide_ok(g, epi_flags);
     return dispatch_flags(g, epi_flags, (hipStream_t)stream);
 }

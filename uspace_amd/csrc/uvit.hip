@@ -120,7 +120,7 @@ Model build_model(const uspace_uvit_config& c) {
 }
 
 struct Workspace {
-    size_t x, xb, h, qkv, f, skips, ctx_bf, ctx_f32, head, xc, part, cbuf, total;
+    size_t x, xb, h, qkv, f, skips, ctx_bf, ctx_f32, head, xc, part, cbuf, splitk, splitk_bytes, total;
 };
 
 Workspace plan_workspace(const uspace_uvit_config& c, const Model& m, int B) {
@@ -140,6 +140,10 @@ Workspace plan_workspace(const uspace_uvit_config& c, const Model& m, int B) {
     w.xc = take(M * D * 2);                          // LayerNorm folding: centred bf16 copy of the residual stream
     w.part = take(M * (size_t)us_cdiv((int)D, 128) * 2 * 4);   // per-row partial sums, one slot per producer N tile
     w.cbuf = take(M * 4);                            // per-row centring constants (row means at the last norm)
+    // fp32 partial sums of the K-split form the GEMM uses for small batches (proj, skip_linear, fc2: N = D)
+    w.splitk_bytes = std::max(std::max(uspace_gemm_split_ws_bytes((int)M, (int)D, (int)D), uspace_gemm_split_ws_bytes((int)M, (int)D, 2 * (int)D)),
+                              uspace_gemm_split_ws_bytes((int)M, (int)D, c.mlp_hidden));
+    w.splitk = take(w.splitk_bytes);
     w.total = off;
     return w;
 }
@@ -251,6 +255,9 @@ extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* bl
     uint16_t* xc = (uint16_t*)(ws + w.xc);
     float* part = (float*)(ws + w.part);
     float* cbuf = (float*)(ws + w.cbuf);
+    uspace_gemm_ext plain{};                          // no LayerNorm folding, only the K-split workspace
+    plain.split_ws = w.splitk_bytes ? ws + w.splitk : nullptr;
+    plain.split_ws_bytes = w.splitk_bytes;
     const bool fold = g_ln_fold.load() != 0 && uspace_gemm_part_slots(B * m.L, c.embed_dim) <= 8;   // consumers read <= 8 partial slots per row
     const size_t MD = (size_t)M * D;
 
@@ -289,6 +296,7 @@ extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* bl
         int np = 1;                                   // partial-sum slots of whoever wrote xc last
         uspace_gemm_ext prod{};                       // producers: centre by cbuf, write xc + part
         prod.row_c = cbuf; prod.out_cen = xc; prod.ld_cen = D; prod.part_out = part; prod.norm_dim = D; prod.eps = 1e-5f;
+        prod.split_ws = plain.split_ws; prod.split_ws_bytes = plain.split_ws_bytes;
         for (int i = 0; i < m.nblocks; ++i) {
             const BlockIdx& b = m.blk[i];
             const bool is_in = i < half, is_out = i > half, is_last = i == m.nblocks - 1;
@@ -319,8 +327,8 @@ extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* bl
             } else {
                 // mid / out blocks: the next consumer is skip_linear (raw bf16 xb) or the head (its own norm)
                 uint16_t* copy = is_last ? nullptr : xb;
-                US_TRY(uspace_gemm_bf16(f, Hd, nullptr, 0, Hd, PH(b.fc2w), Hd, M, D, Hd, copy ? (B_ | R_ | F_ | H_) : (B_ | R_ | F_),
-                                        PF(b.fc2b), x, D, x, D, copy, D, stream));
+                US_TRY(uspace_gemm_bf16_ext(f, Hd, nullptr, 0, Hd, PH(b.fc2w), Hd, M, D, Hd, copy ? (B_ | R_ | F_ | H_) : (B_ | R_ | F_),
+                                            PF(b.fc2b), x, D, x, D, copy, D, &plain, stream));
             }
             if (i == half) {
                 if (io->mid_tap) {
@@ -338,8 +346,8 @@ extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* bl
         if (is_out) {
             // x = skip_linear(cat([x, skip]))  -- two K slabs, skips popped LIFO (libs/uvit.py:159,340)
             const uint16_t* skip = skips + (size_t)(m.nblocks - 1 - i) * MD;
-            US_TRY(uspace_gemm_bf16(xb, D, skip, D, D, PH(b.skip_w), 2 * D, M, D, 2 * D, B_ | F_, PF(b.skip_b),
-                                    nullptr, 0, x, D, nullptr, 0, stream));
+            US_TRY(uspace_gemm_bf16_ext(xb, D, skip, D, D, PH(b.skip_w), 2 * D, M, D, 2 * D, B_ | F_, PF(b.skip_b),
+                                        nullptr, 0, x, D, nullptr, 0, &plain, stream));
         }
         // x += proj(attn(norm1(x)))
         US_TRY(uspace_layernorm_f32_bf16(x, PF(b.n1w), PF(b.n1b), h, M, D, 1e-5f, stream));
@@ -347,16 +355,16 @@ extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* bl
                                 qkv, 3 * D, stream));
         const float* ks = io->key_scale ? io->key_scale + (size_t)i * B * L : nullptr;
         US_TRY(uspace_attention_bf16(qkv, ks, h, B, L, H, stream));
-        US_TRY(uspace_gemm_bf16(h, D, nullptr, 0, D, PH(b.projw), D, M, D, D, B_ | R_ | F_, PF(b.projb), x, D, x, D,
-                                nullptr, 0, stream));
+        US_TRY(uspace_gemm_bf16_ext(h, D, nullptr, 0, D, PH(b.projw), D, M, D, D, B_ | R_ | F_, PF(b.projb), x, D, x, D,
+                                    nullptr, 0, &plain, stream));
         // x += fc2(gelu(fc1(norm2(x))))
         US_TRY(uspace_layernorm_f32_bf16(x, PF(b.n2w), PF(b.n2b), h, M, D, 1e-5f, stream));
         US_TRY(uspace_gemm_bf16(h, D, nullptr, 0, D, PH(b.fc1w), D, M, Hd, D, B_ | G_ | H_, PF(b.fc1b), nullptr, 0,
                                 nullptr, 0, f, Hd, stream));
         // bf16 copy of the block output: the skip (in-blocks) or the next skip_linear's first K slab
         uint16_t* copy = is_in ? skips + (size_t)i * MD : (is_last ? nullptr : xb);
-        US_TRY(uspace_gemm_bf16(f, Hd, nullptr, 0, Hd, PH(b.fc2w), Hd, M, D, Hd, copy ? (B_ | R_ | F_ | H_) : (B_ | R_ | F_),
-                                PF(b.fc2b), x, D, x, D, copy, D, stream));
+        US_TRY(uspace_gemm_bf16_ext(f, Hd, nullptr, 0, Hd, PH(b.fc2w), Hd, M, D, Hd, copy ? (B_ | R_ | F_ | H_) : (B_ | R_ | F_),
+                                    PF(b.fc2b), x, D, x, D, copy, D, &plain, stream));
         if (i == half) {
             if (io->mid_tap) {
                 if (hipMemcpyAsync(io->mid_tap, x, MD * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
