@@ -88,9 +88,10 @@ typedef struct uspace_gemm_ext {
     int norm_dim;           /* LayerNorm width (row length of the producer's output) */
     float eps;
     /* optional (any epilogue without LN_IN / GELU): workspace for the K-split form of small launches -- few output tiles and
-     * a long K are cut into K ranges whose fp32 partial sums go here and are added in a fixed order by a second kernel.
-     * uspace_gemm_split_ws_bytes(M, N, K) is the size it needs (0: the launch is never split); NULL or too small = no split.
-     * Must not alias any operand; 16-byte aligned. */
+     * a long K are cut into K ranges on as many times the CUs, whose fp32 partial sums go here; a second kernel adds them in
+     * a fixed order and applies the epilogue.  uspace_gemm_split_ws_bytes(M, N, K) is the size it needs (0: the launch is
+     * never split); NULL or too small = no split.  Must not alias any operand; 16-byte aligned; one workspace serves one
+     * stream at a time. */
     void* split_ws;
     size_t split_ws_bytes;
 } uspace_gemm_ext;

@@ -49,8 +49,8 @@ struct GemmArgs {
     int ld_cen, np_in;
     float inv_d, eps;
     int wide;   // bf16 outputs (out_bf16, out_cen) allow 16-byte stores: row strides % 8 == 0, bases 16-byte aligned
-    // ring form (NST > 2): K tiles per workgroup (gridDim.y K-splits of nk_split tiles each; split s writes its raw fp32
-    // partial sums to out_f32 + s * split_stride)
+    // ring form (NST > 2, the K-split launches): gridDim.y workgroups per tile, each over nk_split K tiles; split s writes
+    // its raw fp32 sums to out_f32 + s * split_stride; splitk_finish_kernel adds them and applies the real epilogue
     int nk_split;
     long split_stride;
     float* split_ws;          // host side only: workspace for the K-split form (NULL: never split)
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
     constexpr int STAGE_BYTES = TILE_A_BYTES + TILE_W_BYTES + TILE_X_BYTES;
     static_assert(BM % ROWS_PER_ISSUE == 0 && BN % ROWS_PER_ISSUE == 0, "tile/threads mismatch");
     static_assert(TM % 2 == 0 && TN % WM == 0 && (WM == 2 || WM == 4), "wave tile shape");
-    static_assert(NST == 2 || !XTRA, "the ring form has no extra strips");
+    static_assert(NST == 2 || (!XTRA && FLAGS == USPACE_EPI_OUT_F32), "the ring form: plain tiles, raw fp32 partial sums of a K range");
     constexpr int IPT = ISSUES_A + ISSUES_W;    // LDS-DMA instructions per wave and K tile
     static_assert((NST - 1) * IPT < 64, "vmcnt is a 6-bit counter");
 
@@ -454,9 +454,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
         if (MORE && MORE2 && late) stage_a(kt + 2, kt & 1);                                        \
         __builtin_amdgcn_sched_barrier(0);                                                         \
     }
-    // Ring form (small launches, one workgroup per CU: nothing else hides the L2 / HBM latency): same phases, but the
-    // barrier of tile kt waits by count for tile kt+1 only (NST-2 younger tiles stay in flight) and is followed by the
-    // refill of the buffer just freed with tile kt+NST -- both operands NST-1 tiles ahead instead of W less than one
+    // Ring form (K-split launches: a handful of K tiles per workgroup, one workgroup per CU): same phases, but all NST
+    // stages are filled up front, the barrier of tile kt waits by count for tile kt+1 only (NST-2 younger tiles stay in
+    // flight) and is followed by the refill of the buffer just freed with tile kt+NST
 #define KTILE_R(kt, buf, nbuf, MORE, REFILL, WAITN)                                                \
     {                                                                                              \
         const char* cur = smem + (buf) * STAGE_BYTES;                                              \
@@ -797,48 +797,37 @@ int launch(const GemmArgs& a, hipStream_t s, int wg_per_round) {
     return USPACE_OK;
 }
 
-// ---- small launches: 128x128 tiles, one workgroup per CU, ring of 4 LDS stages, optional split along K.
-// With at most one workgroup per CU nothing but the workgroup's own prefetch depth hides the L2 / HBM latency: the
-// two-stage loop above spends ~2 000 cycles per K tile there (512 of them MFMA).  Long K with few tiles (fc2 / skip_linear
-// of a small batch: 36 tiles x 32 K tiles for U-ViT-S at 4 x 257 rows) is cut into S K-ranges (gridDim.y), each writing raw
-// fp32 partial sums to a caller-provided workspace; splitk_finish_kernel adds them in a fixed order and applies the epilogue.
+// ---- small launches: 128x128 tiles that fill a fraction of the CUs, with a long K (fc2 / skip_linear of a small batch:
+// 36 tiles x 32 K tiles for U-ViT-S at 4 x 257 rows).  A lone 128x128 workgroup spends 0.39 us per K tile (its CU's LDS-DMA
+// issue rate, `profiles/r02_gemm_ablation.md` section 7), so the K range is cut into S parts on S times the CUs
+// (gridDim.y), each writing raw fp32 sums to a caller-provided workspace, and splitk_finish_kernel adds them in split
+// order and applies the epilogue.  The split launches use the ring form of the kernel (4 LDS stages, all filled up front:
+// their K loops are a handful of tiles long, mostly start-up latency).  Reducing in the last workgroup to arrive at a
+// counter instead -- one launch -- was slower: three dependent trips through the memory side (ibid.).
 constexpr int RING_NST = 4;
-constexpr int RING_MAX_WG = 256;          // one workgroup per CU (128 KiB of LDS each)
+constexpr int SPLIT_MAX_WG = 256;         // one workgroup per CU (128 KiB of LDS each)
 
-// largest S in {8, 4, 2} with tiles * S <= 256 workgroups and whole K ranges of at least 512 (below that the second
+// K >= 2048: largest S in {8, 4, 2} with tiles * S <= 256 workgroups and K ranges of at least 512 (below that the second
 // kernel costs more than the shorter K loop saves)
 inline int split_factor(int tiles, int K) {
     const int nk = K / BK;
+    if (K < 2048) return 1;               // measured: K = 1024 gains at N = 512 (16.3 -> 13.4 us) and loses at N = 1024 (15.2 -> 18.6)
     for (int S = 8; S >= 2; S >>= 1)
-        if (tiles * S <= RING_MAX_WG && nk % S == 0 && nk / S >= RING_NST && K / S >= 512) return S;
+        if (tiles * S <= SPLIT_MAX_WG && nk % S == 0 && nk / S >= RING_NST && K / S >= 512) return S;
     return 1;
 }
 
-inline bool ring_ok(int M, int N, int K) {
-    return (long)us_cdiv(M, 128) * us_cdiv(N, 128) <= RING_MAX_WG && K / BK >= RING_NST;
-}
-
-template <int FLAGS>
-int launch_ring(const GemmArgs& a, hipStream_t s, int S, float* ws) {
+inline int launch_split(const GemmArgs& a, hipStream_t s, int S) {
     GemmArgs g = a;
     g.tiles_n = us_cdiv(g.N, 128);
     g.tiles_m = us_cdiv(g.M, 128);
     g.m_main = g.M;
     g.n_strip = 0;
     g.nk_split = g.K / BK / S;
-    g.split_stride = 0;
-    if (S > 1) {
-        g.out_f32 = ws;
-        g.ld_f32 = g.N;
-        g.split_stride = (long)g.M * g.N;
-    }
-    const bool rec = g_rec.on && g_rec.flags == FLAGS && g_rec.N == g.N && g_rec.K == g.K && g_rec.used + 2 <= g_rec.cap;
-    if (rec) (void)hipEventRecord(g_rec.ev[g_rec.used], s);
-    hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2, FLAGS, false, RING_NST>), dim3(g.tiles_m * g.tiles_n, S), dim3(256), 0, s, g);
-    if (rec) {
-        (void)hipEventRecord(g_rec.ev[g_rec.used + 1], s);
-        g_rec.used += 2;
-    }
+    g.out_f32 = a.split_ws;
+    g.ld_f32 = g.N;
+    g.split_stride = (long)g.M * g.N;
+    hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2, USPACE_EPI_OUT_F32, false, RING_NST>), dim3(g.tiles_m * g.tiles_n, S), dim3(256), 0, s, g);
     US_CHECK_LAUNCH();
     return USPACE_OK;
 }
@@ -967,18 +956,23 @@ int dispatch_tile(const GemmArgs& a, hipStream_t s) {
     int m1 = 0;
     TileChoice tc = choose_tile(a.M, a.N, &m1);
     if (tc == TILE_SPLIT && (FLAGS & USPACE_EPI_CEN_OUT)) tc = TILE_BIG;   // one partial-sum stride per launch
-    if (tc == TILE_SMALL && ring_ok(a.M, a.N, a.K)) {
-        constexpr bool SPLITTABLE = (FLAGS & (USPACE_EPI_LN_IN | USPACE_EPI_GELU)) == 0;
-        const int tiles = us_cdiv(a.M, 128) * us_cdiv(a.N, 128);
-        const int S = (SPLITTABLE && a.split_ws) ? split_factor(tiles, a.K) : 1;
-        if (S > 1 && (size_t)S * a.M * a.N * 4 <= a.split_ws_bytes) {
-            int rc = launch_ring<USPACE_EPI_OUT_F32>(a, s, S, a.split_ws);
-            if (rc != USPACE_OK) return rc;
-            hipLaunchKernelGGL(splitk_finish_kernel, dim3(a.M), dim3(256), 0, s, a.split_ws, S, (long)a.M * a.N, a, FLAGS, us_cdiv(a.N, 128));
-            US_CHECK_LAUNCH();
-            return USPACE_OK;
+    if constexpr ((FLAGS & (USPACE_EPI_LN_IN | USPACE_EPI_GELU)) == 0) {
+        if (tc == TILE_SMALL && a.split_ws) {
+            const int S = split_factor(us_cdiv(a.M, 128) * us_cdiv(a.N, 128), a.K);
+            if (S > 1 && (size_t)S * a.M * a.N * 4 <= a.split_ws_bytes) {
+                const bool rec = g_rec.on && g_rec.flags == FLAGS && g_rec.N == a.N && g_rec.K == a.K && g_rec.used + 2 <= g_rec.cap;
+                if (rec) (void)hipEventRecord(g_rec.ev[g_rec.used], s);
+                const int rc = launch_split(a, s, S);
+                if (rc != USPACE_OK) return rc;
+                hipLaunchKernelGGL(splitk_finish_kernel, dim3(a.M), dim3(256), 0, s, a.split_ws, S, (long)a.M * a.N, a, FLAGS, us_cdiv(a.N, 128));
+                if (rec) {
+                    (void)hipEventRecord(g_rec.ev[g_rec.used + 1], s);
+                    g_rec.used += 2;
+                }
+                US_CHECK_LAUNCH();
+                return USPACE_OK;
+            }
         }
-        return launch_ring<FLAGS>(a, s, 1, nullptr);
     }
     switch (tc) {
         case TILE_BIG: return launch<256, 256, 2, 4, FLAGS>(a, s, 256);
@@ -1034,7 +1028,7 @@ extern "C" int uspace_gemm_part_slots(int M, int N) {
 extern "C" size_t uspace_gemm_split_ws_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0 || K % BK) return 0;
     int m1 = 0;
-    if (choose_tile(M, N, &m1) != TILE_SMALL || !ring_ok(M, N, K)) return 0;
+    if (choose_tile(M, N, &m1) != TILE_SMALL) return 0;
     const int S = split_factor(us_cdiv(M, 128) * us_cdiv(N, 128), K);
     return S > 1 ? (size_t)S * M * N * 4 : 0;
 }
