@@ -125,7 +125,9 @@ __device__ __forceinline__ void wait_vm() {
 }
 
 template <int BM, int BN, int WM, int WN, int FLAGS, bool XTRA, int NST = 2>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
+// (second launch bound = waves per SIMD: the 4-wave 128x128 form shares a CU with a second workgroup, so its waves must
+// fit 256 registers; one instantiation had grown to 264)
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 2) ? 2 : 1) void gemm_kernel(const GemmArgs g) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr int TM = BM / WM / 16;            // 16-row activation sub-tiles per wave
     constexpr int TN = BN / WN / 16;            // 16-col weight sub-tiles per wave
@@ -316,6 +318,32 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
 
     bf16x8 af0[HM], af1[HM], wf0[TN], wf1[TN], xf0, xf1;
 
+    // per-column epilogue constants of this lane (bias, column sums of the folded weights).  The small tile forms fetch them
+    // before the K loop: their launches are a few K tiles long, and a dependent global load after the loop is 1-2 us of a
+    // 10 us kernel; the 256-row, 256-column forms have no registers to spare for that and K loops long enough not to care
+    constexpr bool LN_IN = (FLAGS & USPACE_EPI_LN_IN) != 0, CEN = (FLAGS & USPACE_EPI_CEN_OUT) != 0;
+    constexpr bool EARLY_EPI = BM * BN <= 256 * 128;
+    f32x4 bias4[TN];
+    f32x4 cs4[LN_IN ? TN : 1];
+    auto load_epi_consts = [&]() {
+        if constexpr (FLAGS & USPACE_EPI_BIAS) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int n = n0 + wn * (BN / WN) + j * 16 + fq * 4;
+                n = n < g.N ? n : g.N - 4;
+                bias4[j] = *(const f32x4*)(g.bias + n);
+            }
+        }
+        if constexpr (LN_IN) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int n = n0 + wn * (BN / WN) + j * 16 + fq * 4;
+                n = n < g.N ? n : g.N - 4;
+                cs4[j] = *(const f32x4*)(g.colsum + n);
+            }
+        }
+    };
+
 #define LOAD_A(dst, base, mh, ck)                                                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < HM; ++i_)                                               \
         dst[i_] = *(const bf16x8*)((base) + a_lds + ((mh) * HM + i_) * 16 * ROW_BYTES + (ck));
@@ -376,6 +404,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
         stage_w(0, 0);
         if (nk > 1) stage_a(1, 1);
         if constexpr (ROWV) fetch_rowv();
+        if constexpr (EARLY_EPI) load_epi_consts();
         __syncthreads();
     }
     if constexpr (ROWV) {
@@ -525,25 +554,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs g) {
 #undef MMA_X
 
     // ---- epilogue: lane holds, for sub-tile (i,j), row m = ..+fr and columns n = ..+4*fq+{0,1,2,3}
-    f32x4 bias4[TN];
-    if constexpr (FLAGS & USPACE_EPI_BIAS) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            int n = n0 + wn * (BN / WN) + j * 16 + fq * 4;
-            n = n < g.N ? n : g.N - 4;
-            bias4[j] = *(const f32x4*)(g.bias + n);
-        }
-    }
-    constexpr bool LN_IN = (FLAGS & USPACE_EPI_LN_IN) != 0, CEN = (FLAGS & USPACE_EPI_CEN_OUT) != 0;
-    f32x4 cs4[LN_IN ? TN : 1];
-    if constexpr (LN_IN) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            int n = n0 + wn * (BN / WN) + j * 16 + fq * 4;
-            n = n < g.N ? n : g.N - 4;
-            cs4[j] = *(const f32x4*)(g.colsum + n);
-        }
-    }
+    if constexpr (!EARLY_EPI) load_epi_consts();
     float ps1 = 0.f, ps2 = 0.f;   // producer: running partial sums of the row being emitted
     float row_d = 0.f, row_r = 1.f, row_cv = 0.f;
     // one accumulator vector = 4 consecutive columns of one row: value (LayerNorm finish, bias), activation, outputs
