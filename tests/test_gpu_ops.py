@@ -118,7 +118,9 @@ def test_layernorm(hip, M, D):
     assert (err <= BF16_EPS * np.abs(ref) * 1.01 + 2e-5).all(), err.max()
 
 
-@pytest.mark.parametrize("B,L,H", [(2, 65, 1), (2, 142, 2), (3, 257, 2), (2, 258, 1), (2, 334, 3), (1, 1, 1), (1, 17, 1)])
+# (B * H <= 64 with at most 17 key tiles runs four workgroups per head, each on a quarter of the query tiles, B * H <= 128 two;
+# (9, 257, 16) is the one-workgroup-per-head form of the large batches)
+@pytest.mark.parametrize("B,L,H", [(2, 65, 1), (2, 142, 2), (3, 257, 2), (2, 258, 1), (2, 334, 3), (1, 1, 1), (1, 17, 1), (9, 257, 16), (5, 257, 16), (4, 257, 8)])
 @pytest.mark.parametrize("scaled", [False, True])
 def test_attention(hip, B, L, H, scaled):
     rng = np.random.default_rng(B * 1000 + L + H)

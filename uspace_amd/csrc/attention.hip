@@ -46,7 +46,9 @@ __device__ __forceinline__ uint2 lds_read_tr16(const char* p) {
 // the tail-tile masks, the tile-skip tests and the V^T stride fold away; LC == 0: generic length.
 // NW = waves per workgroup: 4 when two workgroups fit a CU's LDS (L <= 272), 8 when only one does.
 // CAUSAL: key k is visible to query q iff k <= q (CLIP text transformer); the key_scale edit does not apply there.
-template <int NT, int LC, bool SCALED, int NW, bool CAUSAL = false>
+// QS: workgroups per (batch, head): small batches (B * H of a few dozen on 256 CUs) cut the query tiles of a head over QS
+// workgroups, each staging K and V for itself -- the kernel is latency-bound there, not traffic-bound.
+template <int NT, int LC, bool SCALED, int NW, bool CAUSAL = false, int QS = 1>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void attention_kernel(const bf16_t* __restrict__ qkv,
                                                            const float* __restrict__ key_scale,
                                                            bf16_t* __restrict__ out, int L_rt, int H) {
@@ -62,8 +64,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void attention_kernel(con
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x / H;
-    const int h = blockIdx.x % H;
+    const int bh = QS > 1 ? blockIdx.x / QS : blockIdx.x;
+    const int qwave = QS > 1 ? (int)(blockIdx.x % QS) * NW + wave : wave;   // this wave's first query tile
+    constexpr int QSTEP = NW * QS;                                          // ... and its stride
+    const int b = bh / H;
+    const int h = bh % H;
     const int C3 = 3 * H * DH;
     const bf16_t* base = qkv + (size_t)b * L * C3;
     const bf16_t* gq = base + h * DH;
@@ -119,13 +124,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void attention_kernel(con
         qf[1] = *(const bf16x8*)(gq + (size_t)qrow * C3 + 32 + fq * 8);
     };
     bf16x8 qf[2], qn[2];
-    load_q(wave < n_qt ? wave : 0, qf);
+    load_q(qwave < n_qt ? qwave : 0, qf);
     __syncthreads();   // (drains the LDS-DMA queue) K, V^T, key scales visible
 
 #pragma unroll 1
-    for (int qt = wave; qt < n_qt; qt += NW) {
+    for (int qt = qwave; qt < n_qt; qt += QSTEP) {
         const int q0 = qt * 16;
-        load_q(qt + NW < n_qt ? qt + NW : qt, qn);       // prefetch the next tile's Q fragment
+        load_q(qt + QSTEP < n_qt ? qt + QSTEP : qt, qn);       // prefetch the next tile's Q fragment
         // the K fragments are the same for every query tile: stop the compiler from hoisting all
         // 2*NT of them out of this loop (136+ VGPRs -> scratch spills); LDS re-reads are the point
         int lds_k = 0;
@@ -289,7 +294,19 @@ template <int NT, int LC, bool SCALED, int NW>
 int launch_attn2(const bf16_t* qkv, const float* ks, bf16_t* out, int B, int L, int H, hipStream_t s) {
     constexpr int NP = (NT + 1) / 2;
     const size_t lds = (size_t)NT * 16 * KROW_BYTES + (size_t)NP * 32 * KROW_BYTES + (SCALED ? NT * 16 * 4 : 0);
-    static std::atomic<uint64_t> lds_ok{0};
+    static std::atomic<uint64_t> lds_ok{0}, lds_ok_q4{0}, lds_ok_q2{0};
+    if (NW == 4 && B * H <= 64) {          // a quarter of the CUs or less: four workgroups per head (11.2 -> 6.4 us at B * H = 32)
+        US_TRY(us_opt_in_lds((const void*)attention_kernel<NT, LC, SCALED, NW, false, 4>, 160 * 1024, lds_ok_q4));
+        hipLaunchKernelGGL((attention_kernel<NT, LC, SCALED, NW, false, 4>), dim3(B * H * 4), dim3(64 * NW), lds, s, qkv, ks, out, L, H);
+        US_CHECK_LAUNCH();
+        return USPACE_OK;
+    }
+    if (NW == 4 && B * H <= 128) {         // half of the CUs: two (12.1 -> 8.9 us at B * H = 128; nothing above that)
+        US_TRY(us_opt_in_lds((const void*)attention_kernel<NT, LC, SCALED, NW, false, 2>, 160 * 1024, lds_ok_q2));
+        hipLaunchKernelGGL((attention_kernel<NT, LC, SCALED, NW, false, 2>), dim3(B * H * 2), dim3(64 * NW), lds, s, qkv, ks, out, L, H);
+        US_CHECK_LAUNCH();
+        return USPACE_OK;
+    }
     US_TRY(us_opt_in_lds((const void*)attention_kernel<NT, LC, SCALED, NW>, 160 * 1024, lds_ok));
     hipLaunchKernelGGL((attention_kernel<NT, LC, SCALED, NW>), dim3(B * H), dim3(64 * NW), lds, s, qkv, ks, out, L, H);
     US_CHECK_LAUNCH();
