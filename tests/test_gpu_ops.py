@@ -346,7 +346,8 @@ def test_gemm_tile_configurations_at_full_row_counts(hip, M, N, K, expect):
     (4 * 257, 512, 2048, False),   # U-ViT-S fc2 at batch 4: 36 tiles, K split in 4
     (4 * 257, 1024, 2048, True),   # U-ViT-L skip_linear ([x | skip], two K slabs) at batch 4: 72 tiles, K split in 2
     (4 * 257, 1024, 4096, False),  # U-ViT-L fc2 at batch 4: K split in 2
-    (4 * 257, 1536, 1024, False),  # K too short to split
+    (4 * 257, 1536, 1024, False),  # K too short to split with 108 tiles
+    (4 * 257, 512, 1024, True),    # U-ViT-S skip_linear at batch 4: 36 tiles, K = 1024 split in 2
     (515, 256, 2048, False),       # ragged rows and few tiles: K split in 4
     (2 * 257, 512, 4096, False),   # 20 tiles: K split in 8
 ])
@@ -370,7 +371,7 @@ def test_gemm_small_launches_k_split(hip, M, N, K, two_slabs):
     dA2 = to_dev(np.ascontiguousarray(A[:, K1:]), torch.bfloat16) if two_slabs else None
     dW, db, dR = to_dev(W, torch.bfloat16), to_dev(b), to_dev(R)
     need = lib.uspace_gemm_split_ws_bytes(M, N, K)
-    assert (need > 0) == (K >= 2048), need
+    assert (need > 0) == (K >= 2048 or (K >= 1024 and -(-M // 128) * -(-N // 128) <= 40)), need
     outs = []
     for ws_bytes in ([0, need] if need else [0]):
         x = torch.empty_like(dR)

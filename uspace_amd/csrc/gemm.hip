@@ -818,11 +818,12 @@ int launch(const GemmArgs& a, hipStream_t s, int wg_per_round) {
 constexpr int RING_NST = 4;
 constexpr int SPLIT_MAX_WG = 256;         // one workgroup per CU (128 KiB of LDS each)
 
-// K >= 2048: largest S in {8, 4, 2} with tiles * S <= 256 workgroups and K ranges of at least 512 (below that the second
+// K >= 2048 (1024 for up to 40 tiles): largest S in {8, 4, 2} with tiles * S <= 256 workgroups and K ranges of at least 512 (below that the second
 // kernel costs more than the shorter K loop saves)
 inline int split_factor(int tiles, int K) {
     const int nk = K / BK;
-    if (K < 2048) return 1;               // measured: K = 1024 gains at N = 512 (16.3 -> 13.4 us) and loses at N = 1024 (15.2 -> 18.6)
+    // measured: K = 1024 gains with 36 tiles (N = 512: 16.3 -> 13.4 us) and loses with 72 (N = 1024: 15.2 -> 18.6)
+    if (K < 1024 || (K < 2048 && tiles > 40)) return 1;
     for (int S = 8; S >= 2; S >>= 1)
         if (tiles * S <= SPLIT_MAX_WG && nk % S == 0 && nk / S >= RING_NST && K / S >= 512) return S;
     return 1;
