@@ -471,6 +471,22 @@ def test_gemm_tile_planning_on_headline_shapes():
     assert L.uspace_gemm_tile_choice(0, 64, None) < 0
 
 
+def test_gemm_k_split_workspace_sizes():
+    """uspace_gemm_split_ws_bytes: only launches of 128x128 tiles that leave most CUs idle and have a long K are split
+    (S K ranges, S * M * N fp32 partial sums): the fc2 / skip_linear shapes of the small batches; never the headline shapes."""
+    from uspace_amd import _hip
+    L = _hip.lib()
+    ws = L.uspace_gemm_split_ws_bytes
+    assert ws(4 * 257, 512, 2048) == 4 * 4 * 257 * 512 * 4          # U-ViT-S fc2, batch 4: 36 tiles x 4 ranges
+    assert ws(4 * 257, 512, 1024) == 2 * 4 * 257 * 512 * 4          # ... skip_linear: K = 1024 only with <= 40 tiles
+    assert ws(4 * 257, 1024, 4096) == 2 * 4 * 257 * 1024 * 4        # U-ViT-L fc2, batch 4: 72 tiles x 2 ranges
+    assert ws(4 * 257, 1024, 1024) == 0 and ws(4 * 257, 512, 512) == 0 and ws(4 * 257, 1536, 512) == 0
+    for M in (32 * 257, 64 * 257, 64 * 334):
+        for N, K in ((1024, 4096), (1024, 2048), (512, 2048), (4096, 1024)):
+            assert ws(M, N, K) == 0
+    assert ws(0, 512, 2048) == 0 and ws(1028, 512, 100) == 0
+
+
 def test_gemm_plans_cover_the_rows_and_waste_little_of_a_round():
     """uspace_gemm_plan over the row counts of every BASELINE configuration (B*L: 4*257, 32*257, 32*334, 64*257, 64*334) and
     every output width of the two model sizes: the tile rows plus the 16-row strips cover M exactly, strips never outnumber
