@@ -122,9 +122,18 @@ __device__ __forceinline__ void gelu_erf_batch(f32x4 (&v)[NV]) {
     US_STAGE_END(q)
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-        t[j] = v[j] - q[j];
+        // (inline asm: fmaxf() costs a second v_max per value to quiet NaNs, and the subtraction is not packed by itself)
+        typedef __attribute__((ext_vector_type(2))) float f32x2_;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[j][c] = fmaxf(t[j][c], q[j][c]);
+        for (int c = 0; c < 4; c += 2) {
+            f32x2_ d;
+            const f32x2_ a = {v[j][c], v[j][c + 1]}, b = {q[j][c], q[j][c + 1]};
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+            t[j][c] = d[0];
+            t[j][c + 1] = d[1];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) asm("v_max_f32 %0, %1, %2" : "=v"(v[j][c]) : "v"(t[j][c]), "v"(q[j][c]));
     }
     US_STAGE_END(v)
 }
