@@ -559,7 +559,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 2) ? 2 : 1) v
     float row_d = 0.f, row_r = 1.f, row_cv = 0.f;
     // one accumulator vector = 4 consecutive columns of one row: value (LayerNorm finish, bias), activation, outputs
     auto emit_pre = [&](f32x4 v, const f32x4& b, const f32x4& cs) -> f32x4 {
-        if constexpr (LN_IN) v = (v - row_d * cs) * row_r;
+        // rstd * (acc - d * colsum) + bias as two fused multiply-adds per value: acc * rstd + (bias - (d * rstd) * colsum)
+        if constexpr (LN_IN) {
+            const float dr = -row_d * row_r;
+            if constexpr (FLAGS & USPACE_EPI_BIAS) return v * row_r + (cs * dr + b);
+            else return v * row_r + cs * dr;
+        }
         if constexpr (FLAGS & USPACE_EPI_BIAS) v += b;
         return v;
     };
