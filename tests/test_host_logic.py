@@ -471,6 +471,27 @@ def test_gemm_tile_planning_on_headline_shapes():
     assert L.uspace_gemm_tile_choice(0, 64, None) < 0
 
 
+def test_hot_kernels_have_no_scratch_and_fit_their_register_budget():
+    """Code-object metadata of the built library (tools/kernel_resources.py; no GPU): no GEMM / attention kernel spills to
+    scratch, and every kernel that shares a SIMD between two waves (all but the one-workgroup-per-CU ring form of the K-split)
+    stays within 256 vector registers."""
+    import importlib.util
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("llvm-objdump not available")
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    ks = kr.kernels()
+    names = kr.demangle([k["name"] for k in ks])
+    hot = [(k, n) for k, n in zip(ks, names) if "gemm_kernel" in n or "attention_kernel" in n or "gemm_kernel" in k["name"]]
+    assert len(hot) > 100
+    for k, n in hot:
+        assert k["scratch"] == 0, (n, k)
+        ring = k["lds"] >= 128 * 1024 and k["wg"] == 256            # 4 waves, 128 KiB of LDS: one wave per SIMD
+        assert ring or k["vgpr"] + k["agpr"] <= 256, (n, k)
+    assert not [k for k in ks if k["scratch"] > 256], "a kernel with a large scratch frame"
+
+
 def test_gemm_k_split_workspace_sizes():
     """uspace_gemm_split_ws_bytes: only launches of 128x128 tiles that leave most CUs idle and have a long K are split
     (S K ranges, S * M * N fp32 partial sums): the fc2 / skip_linear shapes of the small batches; never the headline shapes."""
