@@ -492,6 +492,39 @@ def test_hot_kernels_have_no_scratch_and_fit_their_register_budget():
     assert not [k for k in ks if k["scratch"] > 256], "a kernel with a large scratch frame"
 
 
+def test_gemm_plans_on_random_shapes():
+    """Property test of the host-side planner (uspace_gemm_plan / _part_slots / _split_ws_bytes) over random [M, N, K]: the tile
+    rows plus the 16-row strips cover M exactly once, strips never outnumber tile rows, the partial-sum slot count is the number
+    of N tiles of the chosen form, and a K-split workspace is S whole [M, N] fp32 images with S in {2, 4, 8}."""
+    from hypothesis import given, settings, strategies as st
+    from uspace_amd import _hip
+    L = _hip.lib()
+    out = (ctypes.c_int * 8)()
+
+    @settings(max_examples=400, deadline=None)
+    @given(M=st.integers(1, 70000), n4=st.integers(1, 2048), k64=st.integers(1, 128))
+    def check(M, n4, k64):
+        N, K = 4 * n4, 64 * k64
+        assert L.uspace_gemm_plan(M, N, out) == 0
+        choice, split, BM, BN, tm, tn, ns, per_round = list(out)
+        assert choice in (0, 1, 2, 3, 4) and (BM, BN) in ((256, 256), (192, 256), (128, 128), (256, 128))
+        rows = split if choice == 3 else M
+        assert (choice == 3) == (0 < split < M and split % 256 == 0) or choice != 3
+        assert tn == -(-N // BN) and 0 <= ns <= tm
+        if ns:
+            assert tm * BM < rows <= tm * BM + 16 * ns and rows > tm * BM + 16 * (ns - 1)
+        else:
+            assert (tm - 1) * BM < rows <= tm * BM
+        assert L.uspace_gemm_part_slots(M, N) == (-(-N // 128) if choice in (2, 4) else -(-N // 256))
+        ws = L.uspace_gemm_split_ws_bytes(M, N, K)
+        if ws:
+            S = ws // (M * N * 4)
+            assert choice == 2 and ws == S * M * N * 4 and S in (2, 4, 8) and K >= 1024 and (K // 64) % S == 0 and K // S >= 512
+            assert -(-M // 128) * -(-N // 128) * S <= 256
+
+    check()
+
+
 def test_gemm_k_split_workspace_sizes():
     """uspace_gemm_split_ws_bytes: only launches of 128x128 tiles that leave most CUs idle and have a long K are split
     (S K ranges, S * M * N fp32 partial sums): the fc2 / skip_linear shapes of the small batches; never the headline shapes."""
