@@ -43,6 +43,39 @@ def test_gemm_plain_and_transpose_detecting(hip, M, N, K):
     np.testing.assert_allclose(got, ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_gemm_random_shapes_and_epilogues(hip, seed):
+    """Seeded random [M, N, K] (ragged rows, N any multiple of 4 -- not of the 16-column MFMA tile --, 1 to 8 K tiles) with a
+    random supported epilogue (libs/timm.py:106-112, libs/uvit.py:159-161), against the oracle's linear / GELU."""
+    rng = np.random.default_rng(1000 + seed)
+    M = int(rng.integers(1, 5000))
+    N = 4 * int(rng.integers(1, 320))
+    K = 64 * int(rng.integers(1, 9))
+    kind = ["f32", "bias_bf16", "bias_gelu_bf16", "bias_resid_f32", "bias_resid_f32_bf16", "bias_f32", "bf16"][seed % 7]
+    A = bf16_round(_rand(rng, M, K))
+    W = bf16_round(_rand(rng, N, K) * 0.1)
+    b = _rand(rng, N)
+    R = _rand(rng, M, N)
+    ref = C.linear(A, W, b if "bias" in kind else None)
+    if "gelu" in kind:
+        ref = C.gelu(ref)
+    if "resid" in kind:
+        ref = ref + R
+    dA, dW = to_dev(A, torch.bfloat16), to_dev(W, torch.bfloat16)
+    x = to_dev(R).clone() if "resid" in kind else torch.full((M, N), float("nan"), device="cuda")
+    xb = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    hip.gemm(dA, dW, bias=to_dev(b) if "bias" in kind else None, resid=x if "resid" in kind else None, gelu="gelu" in kind,
+             out_f32=x if "f32" in kind else None, out_bf16=xb if "bf16" in kind else None)
+    if "f32" in kind:
+        got = x.cpu().numpy()
+        assert rel_l2(got, ref) < 1e-5, (M, N, K, kind, rel_l2(got, ref))
+        np.testing.assert_allclose(got, ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
+    if "bf16" in kind:
+        gotb = xb.float().cpu().numpy()
+        assert np.isfinite(gotb).all()
+        assert (np.abs(gotb - ref) <= BF16_EPS * np.abs(ref) * 1.01 + 1e-3 * np.abs(ref).max()).all(), (M, N, K, kind)
+
+
 def test_gemm_identity_weight_reproduces_rows(hip):
     # W = I (asymmetric A): output must be A itself, bit-exact in fp32
     rng = np.random.default_rng(0)
