@@ -351,11 +351,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 2) ? 2 : 1) v
     _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_)                                               \
         dst[j_] = *(const bf16x8*)((base) + w_lds + j_ * 16 * ROW_BYTES + (ck));
 #define LOAD_X(dst, base, ck) if (has_x) dst = *(const bf16x8*)((base) + x_lds + (ck));
+#ifndef USPACE_PRIO
+#define USPACE_PRIO 0   /* experiment: 1 = s_setprio(1) around every MFMA group, 2 = waves of the second half at priority 1 throughout */
+#endif
 #define MMA(af, wf, mh, ilo, ihi)                                                                   \
+    if (USPACE_PRIO == 1) __builtin_amdgcn_s_setprio(1);                                            \
     _Pragma("unroll") for (int i_ = (ilo); i_ < (ihi); ++i_)                                        \
         _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_)                                           \
             acc[(mh) * HM + i_][j_] =                                                               \
-                __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j_], af[i_], acc[(mh) * HM + i_][j_], 0, 0, 0);
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j_], af[i_], acc[(mh) * HM + i_][j_], 0, 0, 0); \
+    if (USPACE_PRIO == 1) __builtin_amdgcn_s_setprio(0);
 #define MMA_X(xf, wf)                                                                               \
     if (XTRA && has_x) {                                                                            \
         _Pragma("unroll") for (int j_ = 0; j_ < XN; ++j_)                                           \
@@ -363,6 +368,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 2) ? 2 : 1) v
     }
 
     const int nk = NST > 2 ? g.nk_split : g.K / BK;
+    if (USPACE_PRIO == 2 && wave >= (WM * WN) / 2) __builtin_amdgcn_s_setprio(1);
     // LayerNorm folding: thread t fetches the per-row values of tile row t (main rows, then the 16 strip rows) right
     // behind the first LDS-DMA stages -- their latency overlaps the first tile's -- and parks them in LDS after the barrier
     // (ring form: before the stages, so that the counted wait for the first tile covers them)
