@@ -23,7 +23,7 @@ def timeit(fn, n=30):
 
 
 shapes = [("qkv", 16448, 3072, 1024), ("proj", 16448, 1024, 1024), ("fc1", 16448, 4096, 1024), ("fc2", 16448, 1024, 4096),
-          ("skip", 16448, 1024, 2048), ("8k^3", 8192, 8192, 8192), ("fc1,K=8k", 16384, 4096, 8192)]
+          ("skip", 16448, 1024, 2048), ("4k^3", 4096, 4096, 4096), ("8k^3", 8192, 8192, 8192), ("fc1,K=8k", 16384, 4096, 8192)]
 for n, M, N, K in shapes:
     a = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
     w = (torch.randn(N, K, device="cuda") * 0.02).to(torch.bfloat16)
