@@ -674,6 +674,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 2) ? 2 : 1) v
             if constexpr (FLAGS & USPACE_EPI_GELU) gelu_erf_batch<TN>(v);
 #endif
             uint2 pk[TN], pc[TN];
+            f32x4 s1v = {0.f, 0.f, 0.f, 0.f}, s2v = {0.f, 0.f, 0.f, 0.f};   // CEN: the row's sums as packed vector accumulators
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 if constexpr (FLAGS & USPACE_EPI_OUT_F32) *(f32x4*)(out_f32 + (size_t)m * g.ld_f32 + n0 + wn * (BN / WN) + j * 16 + fq * 4) = v[j];
@@ -683,11 +684,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 2) ? 2 : 1) v
                 }
                 if constexpr (CEN) {
                     const f32x4 vc = v[j] - row_cv;
-                    ps1 += (vc[0] + vc[1]) + (vc[2] + vc[3]);
-                    ps2 += (vc[0] * vc[0] + vc[1] * vc[1]) + (vc[2] * vc[2] + vc[3] * vc[3]);
+                    s1v += vc;
+                    s2v += vc * vc;
                     pc[j].x = pack_bf2(vc[0], vc[1]);
                     pc[j].y = pack_bf2(vc[2], vc[3]);
                 }
+            }
+            if constexpr (CEN) {
+                ps1 = (s1v[0] + s1v[1]) + (s1v[2] + s1v[3]);
+                ps2 = (s2v[0] + s2v[1]) + (s2v[2] + s2v[3]);
             }
 #ifndef USPACE_ABLATE_NOSTORE
 #pragma unroll
