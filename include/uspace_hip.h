@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define USPACE_ABI_VERSION 5
+#define USPACE_ABI_VERSION 6
 
 #define USPACE_OK 0
 #define USPACE_ERR_ARG (-1)         /* bad pointer / size / unsupported shape */
@@ -207,8 +207,9 @@ USPACE_API int uspace_ode_combine(float* out, const float* y, const float* const
                        int n_k, long n, uspace_stream_t stream);
 
 /* Scaled RMS error norm of an embedded Runge-Kutta step:
- *   result[0] = sqrt(mean((err / (atol + rtol * max(|y0|, |y1|)))^2)),  err = sum_i coef[i]*k[i].
- * result is a device float[1]; scratch a device float[>=1024]. */
+ *   result[0] = sqrt(mean((err / (atol + rtol * max(|y0|, |y1|)))^2)),  err = sum_i coef[i]*k[i];
+ *   result[1] = the sum of squares itself (a batch sharded over GPUs all-reduces these sums, not the norms).
+ * result is a device float[2]; scratch a device float[>=1024]. */
 USPACE_API int uspace_ode_error_norm(const float* y0, const float* y1, const float* const* k, const float* coef,
                           int n_k, float rtol, float atol, long n, float* scratch, float* result,
                           uspace_stream_t stream);

@@ -24,6 +24,11 @@ What is pinned:
   big_{S,L}_{u,t}                   seed-regenerated weights (sha256 pinned) -> out, B=2
   euler20_S_u                       BASELINE config 1: 20 fixed Euler steps, B=4, driven by
                                     a plain loop written here around the reference nnet
+  traj_L_u                          BASELINE config 2 (the headline shape) end to end at B=2: 50 fixed Euler steps and
+                                    50 fixed Dormand-Prince steps (FSAL, 301 evaluations) of the reference U-ViT-L,
+                                    both driven by loops written here (flow_matching.py:130-151 selects the solver;
+                                    the integrator itself is torchdiffeq, absent -- the Dormand-Prince loop below uses
+                                    the published tableau, checked against scipy's RK45 in tests/test_host_logic.py)
 """
 import argparse
 import hashlib
@@ -369,6 +374,60 @@ def make_euler20(uvit, timing):
     timing["cfg1_images_per_s"] = 4.0 / float(np.sum(per))
 
 
+# Dormand-Prince 5(4) tableau (Dormand & Prince 1980; the same numbers as scipy.integrate.RK45.A / .B / .C)
+_DP_C = [0.0, 1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0]
+_DP_A = [
+    [],
+    [1 / 5],
+    [3 / 40, 9 / 40],
+    [44 / 45, -56 / 15, 32 / 9],
+    [19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729],
+    [9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656],
+    [35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84],
+]
+
+
+def make_traj_L_u(uvit, timing):
+    """BASELINE.json configs[1] at B=2: the reference U-ViT-L driven through a whole solve, two ways."""
+    m = build_big(uvit, None, "L", "u")
+    g = torch.Generator().manual_seed(INPUT_SEED)
+    B = 2
+    z = torch.randn(B, 4, 32, 32, generator=g)
+    n = 50
+    h = np.float32(1.0) / np.float32(n)
+
+    def f(tk, y):
+        return m(y, expand_t(float(tk), B), None, edit_loc=None)[0]
+
+    t0 = time.perf_counter()
+    y = z.clone()
+    for k in range(n):
+        y = y + float(h) * f(np.float32(k) * h, y)
+    x1_euler = y.clone()
+    timing["traj_L_u_B2_euler50_total_s"] = time.perf_counter() - t0
+
+    t0 = time.perf_counter()
+    y = z.clone()
+    k1 = f(np.float32(0.0), y)
+    nfe = 1
+    for s in range(n):
+        ts = np.float32(s) * h
+        ks = [k1]
+        for i in range(1, 7):
+            yi = y.clone()
+            for j, a in enumerate(_DP_A[i]):
+                if a != 0.0:
+                    yi = yi + float(np.float32(h) * np.float32(a)) * ks[j]
+            ti = np.float32(1.0) if (s == n - 1 and i >= 5) else ts + np.float32(_DP_C[i]) * h
+            ks.append(f(ti, yi))
+            nfe += 1
+            if i == 6:
+                y = yi          # stage 7's argument IS the 5th-order solution (FSAL)
+        k1 = ks[6]
+    timing["traj_L_u_B2_dopri5_50_total_s"] = time.perf_counter() - t0
+    save("traj_L_u.npz", z=z.numpy(), x1_euler50=x1_euler.numpy(), x1_dopri5_50=y.numpy(), n_steps=np.int32(n), nfe_dopri5=np.int32(nfe))
+
+
 def make_attr_directions():
     """tools/utils_attr.py:124-145 cal_delta_direction on synthetic features: mean(pos) - mean(neg) per
     attribute (the direction files the write hook consumes)."""
@@ -484,11 +543,23 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-large", action="store_true")
     ap.add_argument("--only-pca", action="store_true", help="regenerate only pca_components.npz")
+    ap.add_argument("--only-traj", action="store_true", help="regenerate only traj_L_u.npz")
     ap.add_argument("--only-clip", action="store_true", help="regenerate only clip_text_tiny.npz (no reference import needed)")
     args = ap.parse_args()
     if args.only_clip:
         torch.set_grad_enabled(False)
         make_clip_text()
+        return
+    if args.only_traj:
+        uvit, _ = _refshim.load_reference()
+        torch.set_grad_enabled(False)
+        timing = {}
+        make_traj_L_u(uvit, timing)
+        tpath = os.path.join(HERE, "ref_cpu_timing.json")
+        old = json.load(open(tpath))
+        old.update(timing)
+        json.dump(old, open(tpath, "w"), indent=1)
+        print(json.dumps(timing, indent=1))
         return
     if args.only_pca:
         _refshim.load_reference()
@@ -511,6 +582,7 @@ def main():
                       torch=torch.__version__, dtype="float32", note="reference PyTorch-CPU path, this container")
         make_big(uvit, uvit_t2i, timing)
         make_euler20(uvit, timing)
+        make_traj_L_u(uvit, timing)
         with open(os.path.join(HERE, "ref_cpu_timing.json"), "w") as f:
             json.dump(timing, f, indent=1)
         print(json.dumps(timing, indent=1))

@@ -267,3 +267,26 @@ def test_layernorm_fold_survives_large_row_means():
     assert e_sep <= FWD_TOL and e_fold <= FWD_TOL, (e_fold, e_sep)
     assert e_fold <= 1.5 * e_sep + 1e-3, (e_fold, e_sep)          # folding must not be the less accurate path
     assert rel_l2(outs[1].cpu().numpy(), outs[0].cpu().numpy()) <= FWD_TOL
+
+
+@pytest.mark.parametrize("solver,key,nfe", [("euler", "x1_euler50", 50), ("dopri5", "x1_dopri5_50", 301)])
+def test_headline_solve_matches_reference_trajectory(net_L_u, golden_dir, solver, key, nfe):
+    """BASELINE configs[1] end to end: the reference U-ViT-L driven through 50 Euler steps and through 50 fixed Dormand-Prince
+    steps (301 evaluations) at B=2 in the build container (tests/golden/make_golden.py::make_traj_L_u, solver selection as
+    /root/reference/flow_matching.py:130-151).  Here the two latents ride in a batch of 64 -- the exact headline launch shapes
+    (M = 64*257 rows) -- and their end states must match the reference's (trajectories are independent across the batch)."""
+    from uspace_amd.flow_matching import CNF
+    zf = np.load(os.path.join(golden_dir, "traj_L_u.npz"))
+    z = _z(64, seed=21)
+    z[5] = torch.from_numpy(zf["z"][0]).cuda()
+    z[63] = torch.from_numpy(zf["z"][1]).cuda()
+    cnf = CNF(net_L_u)
+    sk = dict(solver="adaptive" if solver == "dopri5" else "fixed", solver_fix="euler", solver_fix_step=0.02,
+              solver_adaptive="dopri5", solver_adaptive_prec=0.01, n_steps=50)
+    x1 = cnf.decode(z, None, dissect_name="none", edit_loc=None, solver_kwargs=sk)
+    assert cnf.last_stats.nfe == nfe == (int(zf["nfe_dopri5"]) if solver == "dopri5" else 50)
+    got = x1[[5, 63]].cpu().numpy()
+    r = rel_l2(got, zf[key])
+    assert r < 5e-3, r                       # SURVEY.md section 7 trajectory gate (bf16 operands, fp32 state)
+    # the two integrators agree with each other to their truncation error, far above this tolerance's noise floor
+    assert np.isfinite(x1.sum().item())

@@ -223,14 +223,15 @@ def test_ode_state_kernels(hip):
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
     y1 = _rand(rng, n)
     scratch = torch.empty(1024, device="cuda")
-    res = torch.empty(1, device="cuda")
+    res = torch.empty(2, device="cuda")          # [rms, raw sum of squares]
     hip.ode_error_norm(to_dev(y), to_dev(y1), [to_dev(k) for k in ks], cs, 1e-3, 1e-4, scratch, res)
     err = np.zeros(n, np.float64)
     for k, c in zip(ks, cs):
         err += c * k.astype(np.float64)
     tol = 1e-4 + 1e-3 * np.maximum(np.abs(y), np.abs(y1))
     want = np.sqrt(np.mean((err / tol) ** 2))
-    assert abs(float(res.item()) - want) / want < 1e-4
+    assert abs(float(res[0].item()) - want) / want < 1e-4
+    assert abs(float(res[1].item()) - want * want * n) / (want * want * n) < 2e-4
 
 
 @pytest.mark.parametrize("B,Ci,Co,H", [(2, 64, 128, 8), (1, 128, 64, 16), (3, 256, 256, 12)])

@@ -160,6 +160,7 @@ def test_batched_write_scales_sweep_equals_sequential_solves(golden_dir):
     net = net.cuda().eval()
     cnf = CNF(net)
     x0 = torch.from_numpy(z["x"]).cuda()
+    spec = O.UViTSpec(img_size=16, patch_size=2, in_chans=4, embed_dim=64, depth=2, num_heads=1)
     scales = [-2.0, -0.5, 0.0, 1.0, 3.0]
     sk = _solver_kwargs(solver_fix_step=0.1)
     with tempfile.TemporaryDirectory() as d:
@@ -177,6 +178,20 @@ def test_batched_write_scales_sweep_equals_sequential_solves(golden_dir):
             plain = cnf.decode(x0, None, dissect_name="none", edit_loc=None, solver_kwargs=sk)
             assert rel_l2(bat[2].cpu().numpy(), plain.cpu().numpy()) < 2e-3
             assert rel_l2(bat[4].cpu().numpy(), plain.cpu().numpy()) > 1e-3
+            # ... and both equal the ORACLE's hooked trajectory, one sequential solve per scale as the reference loop
+            # does (tools/utils_vis.py:189-198 around libs/dissection.py:115-186): the batched form is compared with an
+            # independent statement of the hook, not only with the product's own sequential solves
+            okw = {k: v for k, v in kw.items() if k != "solver_kwargs"}
+            for i, sc in enumerate(scales):
+                f_ref = lambda t, y, sc=sc: O.uvit_forward(spec, sd, y, np.float32(t), write_scale=sc, **okw)
+                ref = OO.solve(f_ref, z["x"], 0.0, 1.0, method="euler", step_size=0.1)
+                assert rel_l2(bat[i].cpu().numpy(), ref) < 1e-2, (loc, sc)
+                assert rel_l2(seq[i].cpu().numpy(), ref) < 1e-2, (loc, sc)
+            ref_plain = OO.solve(lambda t, y: O.uvit_forward(spec, sd, y, np.float32(t), edit_loc=None), z["x"], 0.0, 1.0,
+                                 method="euler", step_size=0.1)
+            edit_size = rel_l2(OO.solve(lambda t, y: O.uvit_forward(spec, sd, y, np.float32(t), write_scale=3.0, **okw),
+                                        z["x"], 0.0, 1.0, method="euler", step_size=0.1), ref_plain)
+            assert edit_size > 1e-3, (loc, edit_size)      # the comparison above is not vacuous: the hook moves the result
     with pytest.raises(ValueError):
         net(x0, torch.tensor(0.2, device="cuda").expand(3), None, dissect_task="uspace_uvit", dissect_name="write_attr",
             t_edit=0.4, write_path_root="/nonexistent", edit_loc="head", ith_attr=1, write_scale=[1.0, 2.0])

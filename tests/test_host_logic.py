@@ -276,6 +276,75 @@ def test_solvers_converge_at_their_order_and_agree():
     np.testing.assert_array_equal(np.array(fixed_grid(-1, 0, 0.01)), OO.grid_points(-1, 0, 0.01))
 
 
+class _F64Ops:
+    """fp64 state arithmetic (test-local) so the tableau constants are compared beyond fp32 rounding."""
+
+    def prepare(self, y):
+        return np.asarray(y, np.float64)
+
+    def combine(self, y, ks, coefs):
+        out = np.asarray(y, np.float64).copy()
+        for k, c in zip(ks, coefs):
+            out += float(c) * k
+        return out
+
+    def scaled_norm(self, y0, y1, ks, coefs, rtol, atol):
+        err = sum(float(c) * k for k, c in zip(ks, coefs))
+        return float(np.sqrt(np.mean((err / (atol + rtol * np.maximum(np.abs(y0), np.abs(y1)))) ** 2)))
+
+
+def test_dopri5_step_is_pinned_to_scipy_rk45():
+    """Independent pin of the integrator arithmetic.  torchdiffeq -- what the reference calls at
+    flow_matching.py:118,140,163,172 -- is absent; scipy.integrate's RK45 is an independent statement of the same
+    Dormand-Prince pair.  Pinned here: the stage abscissae / stage matrix / 5th-order weights (through one whole step: y1
+    and every stage derivative), the dense-output mid-point weights (scipy's interpolant P at theta = 1/2), the dense
+    output against scipy's at other theta to the order of the interpolant, and the error weights up to the one documented
+    difference: torchdiffeq's estimate is -2/3 of the textbook b5 - b4 difference scipy uses (its embedded 4th-order
+    weights are 1951/21600, 22642/50085, ... with -1/60 for the FSAL stage).  NOT pinned by this test: the step-size
+    controller, the initial-step heuristic and the accept rule (they stay "parity unpinned")."""
+    from scipy.integrate import RK45
+    from scipy.integrate._ivp.rk import rk_step
+    from uspace_amd import odeint as oi
+
+    tab = oi._DOPRI5
+    # constants, entry by entry
+    np.testing.assert_allclose([0.0] + tab["alpha"][:-1], RK45.C, rtol=0, atol=1e-15)
+    for i, row in enumerate(tab["beta"][:-1]):
+        np.testing.assert_allclose(row, RK45.A[i + 1][: len(row)], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(tab["beta"][-1], RK45.B, rtol=0, atol=1e-15)          # FSAL row = 5th-order weights
+    np.testing.assert_allclose(tab["c_sol"][:-1], RK45.B, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(tab["c_err"], -2.0 / 3.0 * RK45.E, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(tab["c_mid"], RK45.P @ (0.5 ** np.arange(1, 5)), rtol=0, atol=1e-15)
+
+    # one whole step on a closed-form, non-autonomous, nonlinear field: product code against scipy's rk_step
+    def f(t, y):
+        return -1.3 * y + np.sin(3.0 * t) + 0.4 * np.tanh(y) * np.cos(t)
+
+    y0 = np.random.default_rng(5).standard_normal(24)
+    t0, h = 0.37, 0.11
+    f0 = f(t0, y0)
+    st = oi.Stats()
+    y1, f1, ks, ratio = oi._adaptive_try(f, tab, _F64Ops(), t0, h, y0, f0, 1.0, st, 1e-5, 1e-5)
+    K = np.empty((7, y0.size))
+    y1_ref, f1_ref = rk_step(f, t0, y0, f0, h, RK45.A, RK45.B, RK45.C, K)
+    assert st.nfe == 6
+    np.testing.assert_allclose(y1, y1_ref, rtol=1e-13, atol=1e-14)
+    np.testing.assert_allclose(f1, f1_ref, rtol=1e-13, atol=1e-14)
+    np.testing.assert_allclose(np.stack(ks), K, rtol=1e-12, atol=1e-13)
+    err_ref = -2.0 / 3.0 * (K.T @ RK45.E) * h
+    err = sum(h * c * k for c, k in zip(tab["c_err"], ks))
+    np.testing.assert_allclose(err, err_ref, rtol=1e-10, atol=1e-16)
+    want_ratio = np.sqrt(np.mean((err_ref / (1e-5 + 1e-5 * np.maximum(np.abs(y0), np.abs(y1_ref)))) ** 2))
+    assert abs(ratio - want_ratio) <= 1e-9 * want_ratio
+
+    # dense output: the product's quartic through (y0, y_mid, y1, f0, f1) against scipy's interpolant y0 + h K^T P theta^i
+    for theta in (0.5, 0.25, 0.8, 1.0):
+        got = oi._dense_eval(tab, _F64Ops(), t0, h, y0, y1, f0, f1, ks, t0 + theta * h)
+        ref = y0 + h * (K.T @ (RK45.P @ (theta ** np.arange(1, 5))))
+        # both are 4th-order interpolants that agree at theta = 0, 1/2, 1 in value and at 0, 1 in slope: equal as polynomials
+        np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-12)
+
+
 class _StubNet(torch.nn.Module):
     """CPU stand-in for nnet used only to exercise CNF's solver-selection logic."""
 

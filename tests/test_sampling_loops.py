@@ -48,7 +48,7 @@ def _worker(rank, world, port, out_dir, q):
 
     # ---- sample_for_hspace_vis: sequential sweep vs one batched sweep, same latents (seeded per rank)
     scales = [-1.0, 0.0, 2.0]
-    kw = dict(dissect_name="write_attr", ith_attr=3, seed=5, dataset_name="x")
+    kw = dict(dissect_name="write_attr", ith_attr=3, seed=5, dataset_name="celeba256")
     files = {}
     for mode in ("seq", "sweep"):
         g = torch.Generator().manual_seed(100 + rank)
@@ -71,6 +71,9 @@ def _worker(rank, world, port, out_dir, q):
     with pytest.raises(NotImplementedError):
         sample_for_hspace_vis(acc, out_dir, None, z_shape=(4, 8, 8), n_samples=2, mini_batch_size=1, write_scales=scales,
                               dissect_name="bogus")
+    with pytest.raises(ValueError):     # unknown dataset name, as tools/utils_attr.py:104-111
+        sample_for_hspace_vis(acc, out_dir, lambda **k: torch.zeros(1, 3, 8, 8), z_shape=(4, 8, 8), device="cpu", n_samples=1,
+                              mini_batch_size=1, write_scales=[0.0], dissect_name="write_attr", ith_attr=1, dataset_name="x")
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
@@ -94,11 +97,11 @@ def test_loops_over_two_processes(tmp_path):
     # the batched sweep writes the same grids as the sequential sweep
     seq = sorted(glob.glob(str(tmp_path / "seq" / "*.png")))
     swp = sorted(glob.glob(str(tmp_path / "sweep" / "*.png")))
-    assert len(seq) == len(swp) == 2 and all("_seed5_" in f and f.endswith("attr3_-1.00_0.00_2.00.png") for f in seq)
+    assert len(seq) == len(swp) == 2 and all("_seed5_" in f and f.endswith("_Bags_Under_Eyes-1.00_0.00_2.00.png") for f in seq)
     for a, b in zip(seq, swp):
         ia, ib = np.asarray(Image.open(a)), np.asarray(Image.open(b))
-        # 4 rows (2 processes x 2 latents) of 3 scales, 8x8 images, padding 2
-        assert ia.shape == (4 * 10 + 2, 3 * 10 + 2, 3)
+        # 4 rows (2 processes x 2 latents) of 3 scales, 8x8 images, padding 8 (tools/utils_vis.py:18)
+        assert ia.shape == (4 * 16 + 8, 3 * 16 + 8, 3)
         np.testing.assert_array_equal(ia, ib)
         assert (ia[0] == 255).all() and (ia[:, 0] == 255).all()          # pad_value 1.0 border
 
@@ -113,3 +116,48 @@ def test_make_grid_layout():
         y, x = divmod(k, 3)
         want[1 + 3 * y:3 + 3 * y, 1 + 3 * x:3 + 3 * x] = k
     np.testing.assert_array_equal(g[0].numpy(), want)
+
+
+class _OneProc:
+    num_processes = 1
+    is_main_process = True
+
+    def gather(self, t):
+        return t
+
+
+def test_hspace_vis_reference_calling_convention_with_fixed_latents(tmp_path):
+    """every reference config calls with has_attr=True and fixed_z_path=<root>, which means the latents are in
+    ``<root>.npz`` under "latent" (tools/utils_vis.py:25-35); the grid is written like ToPILImage: mul(255).byte() = truncation
+    (tools/utils_vis.py:249-251); file names carry the attribute names (tools/utils_attr.py:113-121)."""
+    from uspace_amd.tools.utils_attr import get_attr_name_from_attr_id
+    from uspace_amd.tools.utils_vis import load_z_from_dir, sample_for_hspace_vis
+    lat = np.random.default_rng(3).standard_normal((3, 4, 8, 8)).astype(np.float32)
+    root = str(tmp_path / "latents")
+    np.savez(root + ".npz", latent=lat, attr=np.zeros((3, 40), np.int64))
+    np.save(str(tmp_path / "plain.npy"), lat)
+    np.testing.assert_array_equal(load_z_from_dir(root, True, "cpu").numpy(), lat)
+    np.testing.assert_array_equal(load_z_from_dir(root + ".npz", True, "cpu").numpy(), lat)      # documented leniency
+    np.testing.assert_array_equal(load_z_from_dir(str(tmp_path / "plain.npy"), False, "cpu").numpy(), lat)
+    with pytest.raises(FileNotFoundError):
+        load_z_from_dir(str(tmp_path / "nothing"), True, "cpu")
+    seen = []
+
+    def one(input_z, write_scale, batch_id, **k):
+        seen.append(input_z.clone())
+        return torch.full((input_z.shape[0], 3, 4, 4), 0.5)      # 127.5 -> 127 by truncation, 128 by rounding
+
+    kw = dict(dissect_name="write_attr", ith_attr="31_39_20", seed=None, dataset_name="celeba256", has_attr=True)
+    files = sample_for_hspace_vis(_OneProc(), str(tmp_path / "o"), one, z_shape=(4, 8, 8), device="cpu", n_samples=99,
+                                  mini_batch_size=2, write_scales=[0.0, 1.0], fixed_z_path=root, **kw)
+    assert len(files) == 2                                                 # n_samples overridden by len(latents) = 3
+    np.testing.assert_array_equal(torch.cat(seen[::2]).numpy(), lat)       # rows in order, one slice per round
+    assert files[0].endswith("_seedNone_0_Smiling_Young_Male0.00_1.00.png")
+    img = np.asarray(Image.open(files[0]))
+    assert img.shape == (2 * 12 + 8, 2 * 12 + 8, 3) and img[8, 8, 0] == 127 and img[0, 0, 0] == 255
+    with pytest.raises(KeyError):        # the reference indexes kwargs["has_attr"]
+        sample_for_hspace_vis(_OneProc(), str(tmp_path / "o"), one, z_shape=(4, 8, 8), device="cpu", mini_batch_size=2,
+                              write_scales=[0.0], fixed_z_path=root, dissect_name="write_attr", ith_attr=1, dataset_name="ffhq")
+    assert get_attr_name_from_attr_id(1, "ffhq256") == "smile" and get_attr_name_from_attr_id("0_39", "celebamask") == "5_o_Clock_Shadow_Young"
+    with pytest.raises(ValueError):
+        get_attr_name_from_attr_id(1.5, "ffhq")

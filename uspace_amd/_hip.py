@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libuspace_hip.so")
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_OUT_BF16 = 1, 2, 4, 8, 16
 EPI_CEN_OUT, EPI_LN_IN = 32, 64          # uspace_gemm_bf16_ext only (LayerNorm folded through the GEMMs)
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _ERR = {-1: "USPACE_ERR_ARG", -2: "USPACE_ERR_LAUNCH", -3: "USPACE_ERR_WORKSPACE"}
 
@@ -268,6 +268,9 @@ def ode_combine(out, y, ks, coefs):
 
 
 def ode_error_norm(y0, y1, ks, coefs, rtol, atol, scratch, result):
+    """``result``: device float[2] = [rms, sum of squares]."""
+    if result.numel() < 2:
+        raise UspaceHipError("ode_error_norm: result must hold 2 floats (ABI 6)")
     n = len(ks)
     karr = (ctypes.c_void_p * n)(*[k.data_ptr() for k in ks])
     carr = (ctypes.c_float * n)(*[float(c) for c in coefs])

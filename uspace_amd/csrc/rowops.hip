@@ -650,7 +650,11 @@ __global__ __launch_bounds__(256) void ode_err_finish_kernel(const float* __rest
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) result[0] = sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)n);
+    if (threadIdx.x == 0) {
+        const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+        result[0] = sqrtf(tot / (float)n);
+        result[1] = tot;      // the raw sum of squares: what a sharded solve all-reduces (odeint.HipStateOps)
+    }
 }
 
 inline int grid_for(long n_items, int cap = 2048) {

@@ -68,13 +68,13 @@ class Stats:
 
 def allreduce_mean_square(pair, group=None):
     """Global mean of squares from each rank's ``pair`` = [sum of squares, element count] (a 2-element fp64 tensor on the
-    rank's device): ONE small all-reduce; returns a host float.  It is the only collective of an error-controlled solve
-    run with a process group (option B): every rank then takes the accept / reject decisions and the step
-    sizes of the single-process solve over the whole batch.  ``group`` None or True = the default group."""
+    rank's device): ONE small all-reduce and ONE read-back; returns a host float.  It is the only collective of an
+    error-controlled solve run with a process group (option B): every rank then takes the same accept /
+    reject decisions and step sizes, those of a solve over the whole batch.  ``group`` None or True = the default group."""
     import torch.distributed as dist
 
     dist.all_reduce(pair, op=dist.ReduceOp.SUM, group=None if group is True else group)
-    tot, n = float(pair[0].item()), float(pair[1].item())
+    tot, n = pair.tolist()
     return tot / n if n > 0 else 0.0
 
 
@@ -82,9 +82,12 @@ class HipStateOps:
     """fp32 device-tensor arithmetic through libuspace_hip.so.
 
     ``group``: a torch.distributed process group (or True for the default group).  With it the RMS norms that steer an
-    adaptive solve are taken over the batch of ALL ranks, so a batch sharded over GPUs follows the step sequence of the
-    unsharded solve; without it (default) every rank controls its own steps, as the reference does under
-    ``accelerate launch`` (each rank solves its own mini-batch, tools/utils_uvit.py:269-277)."""
+    adaptive solve are taken over the batch of ALL ranks: each rank's raw fp32 sum of squares (second output of
+    uspace_ode_error_norm) and element count are all-reduced in fp64, so every rank makes the same decisions and the
+    sharded solve follows the step sequence of the unsharded one up to the rounding of that sum (the single-GPU kernel adds
+    the same squares in one fp32 reduction tree, the sharded form adds per-rank fp32 sums in fp64: a ratio within ~1e-7 of
+    1.0 can fall on the other side).  Without a group (default) every rank controls its own steps, as the reference does
+    under ``accelerate launch`` (each rank solves its own mini-batch, tools/utils_uvit.py:269-277)."""
 
     def __init__(self, like, group=None):
         import torch
@@ -95,9 +98,10 @@ class HipStateOps:
         self._hip = _hip
         self._torch = torch
         self._scratch = torch.empty(1024, dtype=torch.float32, device=like.device)
-        self._result = torch.empty(1, dtype=torch.float32, device=like.device)
+        self._result = torch.zeros(2, dtype=torch.float32, device=like.device)      # [rms, sum of squares]
         self.group = group
         self._pair = torch.zeros(2, dtype=torch.float64, device=like.device) if group is not None else None
+        self._pair_n = None
 
     def prepare(self, y):
         return y.detach().to(self._torch.float32).contiguous()
@@ -115,11 +119,18 @@ class HipStateOps:
         if n > 0:
             self._hip.ode_error_norm(y0, y1, ks, coefs, rtol, atol, self._scratch, self._result)
         if self.group is None:
-            return float(self._result.item())
-        # (sum of squares, count) of this rank -> global RMS
-        self._pair[0] = (self._result[0].double() ** 2) * n if n > 0 else 0.0
-        self._pair[1] = float(n)
-        return math.sqrt(allreduce_mean_square(self._pair, self.group))
+            return float(self._result[0].item()) if n > 0 else 0.0
+        # (sum of squares, count) of this rank -> global RMS; the count is written to the device only when it changes
+        if n > 0:
+            self._pair[0].copy_(self._result[1])
+        else:
+            self._pair[0].zero_()
+        if self._pair_n != n:
+            self._pair[1].fill_(float(n))
+            self._pair_n = n
+        ms = allreduce_mean_square(self._pair, self.group)     # (the all-reduce overwrites pair[1] with the global count)
+        self._pair_n = None
+        return math.sqrt(ms)
 
 
 def _call(func, t, y, sign, stats):

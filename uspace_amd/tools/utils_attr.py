@@ -15,6 +15,35 @@ import torch
 from .. import _hip
 
 
+# Attribute tables of the two annotated face datasets, in annotation-file column order (list_attr_celeba.txt; the 11 FFHQ
+# columns of the reference's label file).  Only the names used in output file names (tools/utils_attr.py:14-23, 73-85).
+CELEBA_ATTRS = [
+    "5_o_Clock_Shadow", "Arched_Eyebrows", "Attractive", "Bags_Under_Eyes", "Bald", "Bangs", "Big_Lips", "Big_Nose",
+    "Black_Hair", "Blond_Hair", "Blurry", "Brown_Hair", "Bushy_Eyebrows", "Chubby", "Double_Chin", "Eyeglasses", "Goatee",
+    "Gray_Hair", "Heavy_Makeup", "High_Cheekbones", "Male", "Mouth_Slightly_Open", "Mustache", "Narrow_Eyes", "No_Beard",
+    "Oval_Face", "Pale_Skin", "Pointy_Nose", "Receding_Hairline", "Rosy_Cheeks", "Sideburns", "Smiling", "Straight_Hair",
+    "Wavy_Hair", "Wearing_Earrings", "Wearing_Hat", "Wearing_Lipstick", "Wearing_Necklace", "Wearing_Necktie", "Young",
+]
+FFHQ_ATTRS = ["gender", "smile", "no_glasses", "anger", "contempt", "disgust", "fear", "happiness", "neutral", "sadness",
+              "surprise"]
+
+
+def get_attr_name_from_attr_id(ith_attr, dataset_name):
+    """File-name piece for an attribute id or an "a_b_c" id string (tools/utils_attr.py:104-121): names joined by "_";
+    ``ValueError`` for an unknown dataset or id type, like the reference."""
+    if "ffhq" in dataset_name:
+        table = FFHQ_ATTRS
+    elif "celeba" in dataset_name:
+        table = CELEBA_ATTRS
+    else:
+        raise ValueError("unknown dataset_name", dataset_name)
+    if isinstance(ith_attr, (int, np.integer)) and not isinstance(ith_attr, bool):
+        return table[int(ith_attr)]
+    if isinstance(ith_attr, str):
+        return "_".join(table[int(tok)] for tok in ith_attr.split("_"))
+    raise ValueError("unknown ith_attr", ith_attr)
+
+
 class DirectionAccumulator:
     def __init__(self, attr_dim):
         if attr_dim not in (40, 11):       # CelebA-40 / FFHQ-11, the only tables the reference accepts

@@ -12,9 +12,10 @@ import os
 import numpy as np
 import torch
 
+from .utils_attr import get_attr_name_from_attr_id
 from .utils_uvit import amortize
 
-_PADDING = 2
+_PADDING = 8          # tools/utils_vis.py:18
 
 
 def pretty_datetime():
@@ -42,12 +43,27 @@ def make_grid(images, nrow, padding=_PADDING, pad_value=0.0):
     return grid
 
 
-def load_z_from_dir(fixed_z_path, has_attr=False, device=None):
-    """latents.npy / latents.npz as written by the reference's extraction (dissect_lfm.py:224-236)."""
-    z = np.load(fixed_z_path, allow_pickle=False)
-    if hasattr(z, "files"):
-        z = z["latent"] if "latent" in z.files else z[z.files[0]]
-    return torch.from_numpy(np.asarray(z, dtype=np.float32)).to(device)
+def load_z_from_dir(root_path, has_attr=False, device=None):
+    """tools/utils_vis.py:25-35: with ``has_attr`` the latents live in ``root_path + ".npz"`` under the key "latent" (the file
+    the extraction step writes next to the attribute table, dissect_lfm.py:224-236); without it ``root_path`` is a plain
+    ``.npy``.  Leniency beyond the reference: with ``has_attr`` an explicit ``*.npz`` path is accepted as well."""
+    if has_attr:
+        path = root_path + ".npz"
+        if not os.path.exists(path) and str(root_path).endswith(".npz") and os.path.exists(root_path):
+            path = root_path
+        z = np.load(path, allow_pickle=False)["latent"]
+    else:
+        z = np.load(root_path, allow_pickle=False)
+    return torch.from_numpy(np.asarray(z)).to(device)
+
+
+def save_grid_topil(grid, path):
+    """What the reference does with the grid (tools/utils_vis.py:249-251): ``ToPILImage()`` = ``mul(255).byte()`` --
+    TRUNCATION, not the rounding of ``save_image`` -- then ``img.save``.  Values are clamped to [0, 255] first (the
+    reference's ``byte()`` wraps outside that range; its inputs are already clamped by ``unpreprocess``)."""
+    from PIL import Image
+    arr = grid.detach().float().mul(255).clamp_(0, 255).to(torch.uint8).permute(1, 2, 0).to("cpu").numpy()
+    Image.fromarray(arr[:, :, 0] if arr.shape[2] == 1 else arr).save(path)
 
 
 def sample_for_hspace_vis(accelerator, path, sample_fn, unpreprocess_fn=None, padding=_PADDING, pad_value=1.0,
@@ -55,7 +71,6 @@ def sample_for_hspace_vis(accelerator, path, sample_fn, unpreprocess_fn=None, pa
                           fixed_z_path=None, sweep_fn=None, attr_name_fn=None, save_grid_fn=None, generator=None, **kwargs):
     """Same signature and loop as the reference (tools/utils_vis.py:138-255) for ``dissect_name`` in {"read", "write_pca",
     "write_attr", "write_x0"}; returns the list of written files (main process) -- the reference returns None."""
-    from .utils_uvit import save_image
     os.makedirs(path, exist_ok=True)
     unpreprocess_fn = unpreprocess_fn or (lambda v: v)
     idx = 0
@@ -65,7 +80,7 @@ def sample_for_hspace_vis(accelerator, path, sample_fn, unpreprocess_fn=None, pa
     name = kwargs["dissect_name"]
     _latent_z = None
     if name in ("write_pca", "write_attr", "write_x0") and fixed_z_path is not None:
-        _latent_z = load_z_from_dir(fixed_z_path, has_attr=kwargs.get("has_attr", False), device=device)
+        _latent_z = load_z_from_dir(fixed_z_path, has_attr=kwargs["has_attr"], device=device)     # KeyError like the reference
         n_samples = len(_latent_z)
 
     def draw():
@@ -93,13 +108,13 @@ def sample_for_hspace_vis(accelerator, path, sample_fn, unpreprocess_fn=None, pa
             raise NotImplementedError(f"dissect_name should be read or write, but got: {name}")
 
         ith_attr = kwargs.get("ith_attr", None)
-        _attr_name = attr_name_fn(ith_attr, kwargs.get("dataset_name")) if attr_name_fn else f"attr{ith_attr}_"
+        _attr_name = (attr_name_fn or get_attr_name_from_attr_id)(ith_attr, kwargs["dataset_name"])
         samples = accelerator.gather(samples.contiguous())
         if accelerator.is_main_process:
             scales = "_".join(f"{s:.2f}" for s in (write_scales or []))
             img_path = os.path.join(path, f"{pretty_datetime()}_seed{_seed}_{idx}_{_attr_name}{scales}.png")
             grid = make_grid(samples, nrow=len(write_scales) if write_scales else 8, padding=padding, pad_value=pad_value)
-            (save_grid_fn or save_image)(grid, img_path)
+            (save_grid_fn or save_grid_topil)(grid, img_path)
             written.append(img_path)
         idx += 1
     return written
