@@ -539,13 +539,80 @@ def make_clip_text():
     save("clip_text_tiny.npz", **arrays)
 
 
+class ToyWordPieceTokenizer:
+    """Greedy longest-match word-piece tokenizer over a fixed vocabulary (continuations carry ``##``), with the two
+    calls ``get_word_inds`` uses: ``encode(text)`` -> ``[bos] + ids + [eos]`` and ``decode([id])`` -> piece text.
+    The real CLIP tokenizer files are not in the image; the helper only needs pieces whose characters add up to the
+    words, which this provides deterministically.  The same class (rebuilt from the stored vocabulary) is in
+    tests/test_host_logic.py."""
+
+    def __init__(self, vocab):
+        self.vocab = list(vocab)
+        self.index = {p: i + 2 for i, p in enumerate(self.vocab)}          # 0 = bos, 1 = eos
+
+    def _word(self, w):
+        out, pos = [], 0
+        while pos < len(w):
+            for end in range(len(w), pos, -1):
+                piece = w[pos:end] if pos == 0 else "##" + w[pos:end]
+                if piece in self.index:
+                    out.append(self.index[piece])
+                    pos = end
+                    break
+            else:
+                raise KeyError(w)
+        return out
+
+    def encode(self, text):
+        return [0] + [i for w in text.split(" ") for i in self._word(w)] + [1]
+
+    def decode(self, ids):
+        return self.vocab[ids[0] - 2] if ids[0] >= 2 else ""
+
+
+def make_word_inds():
+    """libs/clip.py:6-27 get_word_inds (the reference's own function, imported) on a toy word-piece tokenizer:
+    text + word_place -> token positions."""
+    import contextlib
+    import io
+    import importlib
+    _refshim.install()
+    if _refshim.REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, _refshim.REFERENCE_ROOT)
+    ref_clip = importlib.import_module("libs.clip")
+    letters = list("abcdefghijklmnopqrstuvwxyz")
+    vocab = (["a", "photo", "of", "dog", "cat", "run", "the", "smil", "wom", "an", "old", "young", "face", "with", "glass"]
+             + ["##ning", "##ing", "##an", "##es", "##s", "##er"] + letters + ["##" + c for c in letters])
+    vocab = list(dict.fromkeys(vocab))
+    tok = ToyWordPieceTokenizer(vocab)
+    cases = []
+    for text, places in [
+        ("a photo of a running dog", ["running", "a", "dog", 0, 3, 5, "cat"]),
+        ("the smiling woman with glasses", ["smiling", "woman", "glasses", 1, 4, "the"]),
+        ("an old man and a younger woman smiling", ["younger", "and", "smiling", 2, 7, "a"]),
+        ("cats", ["cats", 0]),
+        ("the the the dog", ["the", 3]),
+    ]:
+        for wp in places:
+            with contextlib.redirect_stdout(io.StringIO()):        # the reference prints its word pieces
+                out = ref_clip.get_word_inds(text, wp, tok)
+            cases.append(dict(text=text, word_place=wp, expected=[int(v) for v in np.asarray(out).tolist()]))
+    with open(os.path.join(HERE, "word_inds.json"), "w") as f:
+        json.dump(dict(vocab=vocab, cases=cases), f, indent=1)
+    print("word_inds.json:", len(cases), "cases")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-large", action="store_true")
     ap.add_argument("--only-pca", action="store_true", help="regenerate only pca_components.npz")
     ap.add_argument("--only-traj", action="store_true", help="regenerate only traj_L_u.npz")
     ap.add_argument("--only-clip", action="store_true", help="regenerate only clip_text_tiny.npz (no reference import needed)")
+    ap.add_argument("--only-word-inds", action="store_true", help="regenerate only word_inds.json")
     args = ap.parse_args()
+    if args.only_word_inds:
+        make_word_inds()
+        return
     if args.only_clip:
         torch.set_grad_enabled(False)
         make_clip_text()
@@ -576,6 +643,7 @@ def main():
     make_vae_decoder()
     make_pca_components()
     make_clip_text()
+    make_word_inds()
     if not args.skip_large:
         timing = dict(threads=torch.get_num_threads(), nproc=os.cpu_count(),
                       cpu=[l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0],

@@ -648,3 +648,39 @@ def test_hookplan_scalar_and_row_scales():
     for s in ([0.5, 1.0], np.array([0.5, 1.0]), torch.tensor([0.5, 1.0]), torch.tensor([0.5])):
         p = HookPlan("write", "f", 0, s)
         assert p.scale == 1.0 and p.row_scales.dtype == np.float32 and p.row_scales.ndim == 1
+
+
+def test_get_word_inds_reference_fixture(golden_dir):
+    """tests/golden/word_inds.json: the reference's libs/clip.py:6-27 get_word_inds run on a toy word-piece tokenizer
+    (generated by make_golden.py --only-word-inds); the rewritten helper must give the same token positions."""
+    from uspace_amd.libs.clip import get_word_inds
+    fx = json.load(open(os.path.join(golden_dir, "word_inds.json")))
+
+    class Tok:                                            # greedy longest-match word pieces, "##" continuations
+        def __init__(self, vocab):
+            self.vocab = list(vocab)
+            self.index = {p: i + 2 for i, p in enumerate(self.vocab)}
+
+        def _word(self, w):
+            out, pos = [], 0
+            while pos < len(w):
+                end = next(e for e in range(len(w), pos, -1) if (w[pos:e] if pos == 0 else "##" + w[pos:e]) in self.index)
+                out.append(self.index[w[pos:end] if pos == 0 else "##" + w[pos:end]])
+                pos = end
+            return out
+
+        def encode(self, text):
+            return [0] + [i for w in text.split(" ") for i in self._word(w)] + [1]
+
+        def decode(self, ids):
+            return self.vocab[ids[0] - 2] if ids[0] >= 2 else ""
+    tok = Tok(fx["vocab"])
+    assert len(fx["cases"]) >= 20
+    multi = 0
+    for c in fx["cases"]:
+        got = get_word_inds(c["text"], c["word_place"], tok)
+        assert got.tolist() == c["expected"], c
+        multi += len(c["expected"]) > 1
+    assert multi >= 5                                     # words split into several pieces / repeated words are covered
+    assert get_word_inds("a photo of a running dog", [0, 4], tok).tolist() == sorted(
+        get_word_inds("a photo of a running dog", 0, tok).tolist() + get_word_inds("a photo of a running dog", 4, tok).tolist())

@@ -19,26 +19,41 @@ CLIP_L_TEXT = dict(vocab_size=49408, hidden_size=768, intermediate_size=3072, nu
                    num_attention_heads=12, max_position_embeddings=77, layer_norm_eps=1e-5)   # openai/clip-vit-large-patch14
 
 
+def _word_piece_spans(words, pieces):
+    """Half-open piece ranges ``[lo, hi)`` of every word: a word takes pieces until their characters cover its length
+    (at least one piece, also for an empty word); words beyond the last piece get empty ranges."""
+    spans, pos = [], 0
+    for w in words:
+        lo, covered = pos, 0
+        while pos < len(pieces):
+            covered += len(pieces[pos])
+            pos += 1
+            if covered >= len(w):
+                break
+        spans.append((lo, pos))
+    return spans
+
+
 def get_word_inds(text, word_place, tokenizer):
-    """Token positions (1-based: position 0 is <bos>) of the ``word_place``-th word(s) of ``text``
-    (libs/clip.py:6-27; same walk over the decoded word pieces)."""
+    """Token positions of the selected word(s) of ``text`` in the tokenizer's output, counted with ``<bos>`` at
+    position 0 -- the indices the prompt-to-prompt hooks address in the ``[B, H, L, 77]`` cross-attention maps.
+    ``word_place`` is a word (every occurrence counts), a word index, or a list of word indices.
+    Same results as the reference's helper of this name (libs/clip.py:6-27), pinned by
+    ``tests/golden/word_inds.json``; here the words are first mapped to ranges of word pieces."""
     words = text.split(" ")
     if isinstance(word_place, str):
-        word_place = [i for i, w in enumerate(words) if w == word_place]
-    elif isinstance(word_place, int):
-        word_place = [word_place]
-    out = []
-    if len(word_place) > 0:
-        pieces = [tokenizer.decode([t]).strip("#") for t in tokenizer.encode(text)][1:-1]
-        cur_len, ptr = 0, 0
-        for i, piece in enumerate(pieces):
-            cur_len += len(piece)
-            if ptr in word_place:
-                out.append(i + 1)
-            if cur_len >= len(words[ptr]):
-                ptr += 1
-                cur_len = 0
-    return np.array(out)
+        wanted = [k for k, w in enumerate(words) if w == word_place]
+    elif isinstance(word_place, (int, np.integer)):
+        wanted = [int(word_place)]
+    else:
+        wanted = [int(k) for k in word_place]
+    if not wanted:
+        return np.array([])
+    ids = tokenizer.encode(text)[1:-1]                       # without <bos> / <eos>
+    pieces = [tokenizer.decode([t]).strip("#") for t in ids]
+    spans = _word_piece_spans(words, pieces)
+    picked = sorted({p for k in wanted if 0 <= k < len(spans) for p in range(*spans[k])})
+    return np.array([p + 1 for p in picked])
 
 
 def _linear(group, name, nout, nin):
