@@ -2,7 +2,7 @@
 // counted vmcnt + raw s_barrier.  Two independent workgroups share a CU (2 waves per SIMD from different
 // workgroups), so one workgroup's prologue / epilogue runs under the other's K loop.
 #pragma once
-#include "../../uspace_amd/csrc/common.h"
+#include "../../../uspace_amd/csrc/common.h"
 
 namespace k2 {
 

@@ -7,7 +7,7 @@
 // set's epilogue (VALU + stores, split into E chunks of one barrier step each) runs while the other set keeps the
 // matrix pipe busy.  Staging traffic per FLOP is the same as for a 256 x 256 tile.
 #pragma once
-#include "../../uspace_amd/csrc/common.h"
+#include "../../../uspace_amd/csrc/common.h"
 
 namespace k3 {
 

@@ -119,9 +119,11 @@ __device__ __forceinline__ int lds_off(int r, int c) { return r * ROW_BYTES + ((
 // at the scheduling barriers of the K loop).  Round 1 gave every workgroup ceil(64/64) = 1 row, i.e. 15/16 of an MFMA
 // tile wasted in each of them: +6 % matrix work everywhere.
 // ------------------------------------------------------------------------------------------
+// counted wait for this wave's LDS-DMA of the next tile AND for its outstanding LDS fragment reads: the raw s_barrier
+// that follows frees the buffer those reads came from (gfx950 inserts no wait of its own before s_barrier)
 template <int N>
 __device__ __forceinline__ void wait_vm() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 
 template <int BM, int BN, int WM, int WN, int FLAGS, bool XTRA, int NST = 2>
@@ -351,16 +353,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 2) ? 2 : 1) v
     _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_)                                               \
         dst[j_] = *(const bf16x8*)((base) + w_lds + j_ * 16 * ROW_BYTES + (ck));
 #define LOAD_X(dst, base, ck) if (has_x) dst = *(const bf16x8*)((base) + x_lds + (ck));
-#ifndef USPACE_PRIO
-#define USPACE_PRIO 0   /* experiment: 1 = s_setprio(1) around every MFMA group, 2 = waves of the second half at priority 1 throughout */
-#endif
 #define MMA(af, wf, mh, ilo, ihi)                                                                   \
-    if (USPACE_PRIO == 1) __builtin_amdgcn_s_setprio(1);                                            \
     _Pragma("unroll") for (int i_ = (ilo); i_ < (ihi); ++i_)                                        \
         _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_)                                           \
             acc[(mh) * HM + i_][j_] =                                                               \
-                __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j_], af[i_], acc[(mh) * HM + i_][j_], 0, 0, 0); \
-    if (USPACE_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j_], af[i_], acc[(mh) * HM + i_][j_], 0, 0, 0);
 #define MMA_X(xf, wf)                                                                               \
     if (XTRA && has_x) {                                                                            \
         _Pragma("unroll") for (int j_ = 0; j_ < XN; ++j_)                                           \
@@ -368,7 +365,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 2) ? 2 : 1) v
     }
 
     const int nk = NST > 2 ? g.nk_split : g.K / BK;
-    if (USPACE_PRIO == 2 && wave >= (WM * WN) / 2) __builtin_amdgcn_s_setprio(1);
     // LayerNorm folding: thread t fetches the per-row values of tile row t (main rows, then the 16 strip rows) right
     // behind the first LDS-DMA stages -- their latency overlaps the first tile's -- and parks them in LDS after the barrier
     // (ring form: before the stages, so that the counted wait for the first tile covers them)
@@ -439,24 +435,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 2) ? 2 : 1) v
     LOAD_W(wf0, smem, c_k0)
     if constexpr (XTRA) { LOAD_X(xf0, smem, c_k0) }
 
-#ifndef USPACE_STAG
-#define USPACE_STAG 0
-#endif
-    // USPACE_STAG (experiment): 1 = the second wave of every SIMD (waves 4-7) issues its LDS-DMA after its remaining
-    // MFMAs instead of before them, so the two waves of a SIMD do not issue DMA at the same moment
-    const bool late = USPACE_STAG != 0 && wave >= (WM * WN) / 2;
 #define KTILE(kt, MORE, MORE2)                                                                     \
     {                                                                                              \
         const char* cur = smem + (kt & 1) * STAGE_BYTES;                                           \
         MMA(af0, wf0, 0, 0, 1)                                                                     \
         MMA_X(xf0, wf0)                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        if (MORE && !late) stage_w(kt + 1, (kt + 1) & 1);                                          \
+        if (MORE) stage_w(kt + 1, (kt + 1) & 1);                                                   \
         LOAD_A(af1, cur, 1, c_k0)                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         MMA(af0, wf0, 0, 1, HM)                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        if (MORE && late) stage_w(kt + 1, (kt + 1) & 1);                                           \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         MMA(af1, wf0, 1, 0, 1)                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                         \
@@ -477,7 +465,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 2) ? 2 : 1) v
         __builtin_amdgcn_sched_barrier(0);                                                         \
         if (MORE) {                                                                                \
             __syncthreads(); /* tile kt+1 landed for everyone; buffer kt&1 is free */              \
-            if (MORE2 && !late) stage_a(kt + 2, kt & 1);                                           \
+            if (MORE2) stage_a(kt + 2, kt & 1);                                                    \
             const char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;                                 \
             LOAD_A(af0, nxt, 0, c_k0)                                                              \
             LOAD_W(wf0, nxt, c_k0)                                                                 \
@@ -485,8 +473,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 2) ? 2 : 1) v
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         MMA(af1, wf1, 1, HM / 2, HM)                                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        if (MORE && MORE2 && late) stage_a(kt + 2, kt & 1);                                        \
         __builtin_amdgcn_sched_barrier(0);                                                         \
     }
     // Ring form (K-split launches: a handful of K tiles per workgroup, one workgroup per CU): same phases, but all NST
@@ -979,11 +965,20 @@ TileChoice choose_tile(int M, int N, int* split_rows) {
     return best == cost_mid ? TILE_MID : TILE_SMALL;
 }
 
+// Producers of folded-LayerNorm partial sums (CEN_OUT) write one (sum, sum of squares) pair per row and N tile, and the
+// consumers read at most 8 of them: one partial-sum stride per launch (no split form), and no 128-wide tiles when that
+// would make more than 8 slots (embed_dim > 1024: the 256-wide form halves the slot count, as before the 256x128 form existed)
+inline TileChoice producer_tile(TileChoice tc, int N) {
+    if (tc == TILE_SPLIT) return TILE_BIG;
+    if (tc == TILE_TALL && us_cdiv(N, 128) > 8) return TILE_BIG;
+    return tc;
+}
+
 template <int FLAGS>
 int dispatch_tile(const GemmArgs& a, hipStream_t s) {
     int m1 = 0;
     TileChoice tc = choose_tile(a.M, a.N, &m1);
-    if (tc == TILE_SPLIT && (FLAGS & USPACE_EPI_CEN_OUT)) tc = TILE_BIG;   // one partial-sum stride per launch
+    if constexpr ((FLAGS & USPACE_EPI_CEN_OUT) != 0) tc = producer_tile(tc, a.N);
     if constexpr ((FLAGS & (USPACE_EPI_LN_IN | USPACE_EPI_GELU)) == 0) {
         if (tc == TILE_SMALL && a.split_ws) {
             const int S = split_factor(us_cdiv(a.M, 128) * us_cdiv(a.N, 128), a.K);
@@ -1049,8 +1044,8 @@ int wide_ok(const GemmArgs& g, int epi_flags) {
 extern "C" int uspace_gemm_part_slots(int M, int N) {
     if (M <= 0 || N <= 0) return USPACE_ERR_ARG;
     int m1 = 0;
-    TileChoice tc = choose_tile(M, N, &m1);
-    return us_cdiv(N, (tc == TILE_SMALL || tc == TILE_TALL) ? 128 : 256);     // producers never take the split form
+    const TileChoice tc = producer_tile(choose_tile(M, N, &m1), N);
+    return us_cdiv(N, (tc == TILE_SMALL || tc == TILE_TALL) ? 128 : 256);
 }
 
 extern "C" size_t uspace_gemm_split_ws_bytes(int M, int N, int K) {
