@@ -106,8 +106,70 @@ def cpu_baseline(model_key, nfe, budget_s=12.0):
     per_fwd = el / reps
     lib.oracle_set_threads(max_threads)
     return dict(value=Bs / (per_fwd * nfe), unit="images/sec", cores=int(threads), kind="port",
+                note="unoptimised C/OpenMP restatement (oracle/ops.c): a correctness checker timed for context, not a tuned CPU "
+                     "implementation; the reference's own PyTorch-CPU path is faster per core (reference_pytorch_cpu below)",
                 sample=f"{reps} fp32 forwards of batch {Bs} of the C/OpenMP oracle port ({per_fwd:.2f} s each), "
                        f"extrapolated linearly to {nfe} NFE per solve; host {os.cpu_count()} logical CPUs")
+
+
+def _gemm_role(flags, N, K, D):
+    if K == 2 * D:
+        return "skip_linear"
+    if K == 4 * D:
+        return "fc2"
+    if N == 3 * D:
+        return "qkv"
+    if N == 4 * D:
+        return "fc1"
+    if N == D and K == D:
+        return "proj"
+    return "other"
+
+
+def roofline_rows(recs, D):
+    """bench.py's roofline_all: one row per distinct (kernel kind, epilogue flags, M, N, K) of the recorded eager solve, priced
+    against BOTH roofs (dense bf16 MFMA peak; HBM peak with the launch's ALGORITHMIC bytes: operands once + outputs once)."""
+    from uspace_amd import _hip
+    rows = []
+    for r in recs:
+        n, avg_s = r["launches"], r["total_ms"] / max(r["launches"], 1) / 1e3
+        if r["kind"] == 0:
+            M, N, K, f = r["M"], r["N"], r["K"], r["flags"]
+            flops = 2.0 * M * N * K
+            byts = 2.0 * M * K + 2.0 * N * K
+            byts += 4.0 * M * N * (bool(f & _hip.EPI_RESIDUAL) + bool(f & _hip.EPI_OUT_F32))
+            byts += 2.0 * M * N * (bool(f & _hip.EPI_OUT_BF16) + bool(f & _hip.EPI_CEN_OUT))
+            names = [nm for nm, bit in (("LN_IN", _hip.EPI_LN_IN), ("BIAS", _hip.EPI_BIAS), ("GELU", _hip.EPI_GELU), ("RESIDUAL", _hip.EPI_RESIDUAL),
+                                        ("OUT_F32", _hip.EPI_OUT_F32), ("OUT_BF16", _hip.EPI_OUT_BF16), ("CEN_OUT", _hip.EPI_CEN_OUT)) if f & bit]
+            row = dict(kernel="gemm_kernel", role=_gemm_role(f, N, K, D), epi="|".join(names), epi_flags=f, M=M, N=N, K=K)
+        else:
+            BH, L, hd = r["M"], r["N"], r["K"]
+            flops = 4.0 * L * L * hd * BH
+            byts = 2.0 * BH * L * hd * 4                      # q, k, v read + output written, bf16
+            row = dict(kernel="attention_kernel", role="attention", epi="key_scale" if r["flags"] else "", epi_flags=r["flags"], M=BH, N=L, K=hd)
+        tf, gbs = flops / avg_s / 1e12, byts / avg_s / 1e9
+        row.update(launches=n, avg_us=1e6 * avg_s, flops_per_launch=flops, algorithmic_bytes_per_launch=byts, tflops=tf, gbs=gbs,
+                   frac_mfma=tf / MFMA_BF16_PEAK_TFLOPS, frac_hbm=gbs / HBM_PEAK_GBS,
+                   bound="mfma" if tf / MFMA_BF16_PEAK_TFLOPS >= gbs / HBM_PEAK_GBS else "hbm")
+        rows.append(row)
+    rows.sort(key=lambda q: -q["avg_us"] * q["launches"])
+    return rows
+
+
+def fc1_traffic(model, B, tile):
+    """HBM bytes per fc1 launch from the committed PMC pass (profiles/fc1_traffic.json) -- only when that pass was taken on the
+    gemm.hip that is being benchmarked (sha256 of the source) and on the same workload and tile form; otherwise null."""
+    import hashlib
+    tp = os.path.join(ROOT, "profiles", "fc1_traffic.json")
+    if not os.path.exists(tp):
+        return None, "no committed PMC pass"
+    t = json.load(open(tp))
+    sha = hashlib.sha256(open(os.path.join(ROOT, "uspace_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()
+    if t.get("gemm_hip_sha256") != sha:
+        return None, f"profiles/fc1_traffic.json was measured on another gemm.hip ({str(t.get('gemm_hip_sha256'))[:12]} != {sha[:12]}): dropped"
+    if t.get("model") != model or t.get("batch") != B or list(t.get("tile", [])) != list(tile):
+        return None, "profiles/fc1_traffic.json was measured on another workload / tile form: dropped"
+    return t.get("hbm_bytes_per_launch"), f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of {t.get('source')}, gemm.hip {sha[:12]}"
 
 
 # BASELINE.json configs[i-1] -> workload; "dopri5" = 50 fixed Dormand-Prince steps (301 NFE), "euler" = 50 Euler steps
@@ -124,10 +186,35 @@ def hook_kwargs(net, tmpdir):
     """Synthetic direction tables of SURVEY.md 8(d): delta_{t:.2f}.npy [40, L, D] ~ N(0, 0.01^2), seed 11."""
     rng = np.random.default_rng(11)
     table = (rng.standard_normal((40, net.seq_len, net.embed_dim)) * 0.01).astype(np.float32)
-    for k in range(1, 101):
-        np.save(os.path.join(tmpdir, f"delta_{k / 100:.2f}.npy"), table)
+    # the hook reads delta_{t:.2f}.npy for t <= t_edit only: one file on disk, the other names are hard links to it
+    # (round 2 wrote 100 copies of 42 MB per rank, often into RAM-backed tmpfs)
+    first = os.path.join(tmpdir, "delta_0.01.npy")
+    np.save(first, table)
+    for k in range(2, 42):
+        dst = os.path.join(tmpdir, f"delta_{k / 100:.2f}.npy")
+        try:
+            os.link(first, dst)
+        except OSError:
+            np.save(dst, table)
     return dict(dissect_task="uspace_uvit", dissect_name="write_attr", edit_loc="mid", t_edit=0.4, write_scale=1.0,
                 ith_attr="31_39_20", write_path_root=tmpdir)
+
+
+def relaunch_argv(gpus, port, argv):
+    """The one-rank-per-GPU launch of this script on one node (the form the driver uses for N > 1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def rank_env(gpus, env=None):
+    """(world, rank, local_rank) from the launcher's environment; the world size must be the --gpus that was asked for."""
+    env = os.environ if env is None else env
+    world, rank, local_rank = int(env.get("WORLD_SIZE", "1")), int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", "0"))
+    if world != gpus:
+        raise SystemExit(f"bench.py: --gpus {gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {gpus})")
+    if not (0 <= rank < world and 0 <= local_rank < world):
+        raise SystemExit(f"bench.py: RANK={rank} LOCAL_RANK={local_rank} outside WORLD_SIZE={world}")
+    return world, rank, local_rank
 
 
 def main():
@@ -155,13 +242,12 @@ def main():
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
-        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-                                   f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                                   os.path.abspath(__file__)] + sys.argv[1:])
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        argv = relaunch_argv(args.gpus, port, sys.argv[1:])
+        if os.environ.get("USPACE_BENCH_PRINT_RELAUNCH") == "1":      # tests: show the command instead of running it
+            print(json.dumps(argv))
+            return
+        os.execvp(argv[0], argv)
+    world, rank, local_rank = rank_env(args.gpus)
     assert torch.cuda.is_available(), "bench.py needs ROCm devices"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -238,19 +324,19 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt, median_ms = float(tt[0].item()), float(tt[1].item())
 
-        # ---- outside the timed region: roofline of the dominant kernel.  One more solve with eager launches and HIP
-        #      events recorded (by the library, on the launching stream) around every fc1 launch
+        # ---- outside the timed region: rooflines.  One more solve with eager launches and HIP events recorded (by the
+        #      library, on the launching stream) around every GEMM and attention launch
         D, Hd = cfg["embed_dim"], 4 * cfg["embed_dim"]
         fold = _hip.lib().uspace_uvit_get_ln_fold() != 0       # norm2 folded into fc1 (default) or a separate launch
         fc1_flags = _hip.EPI_BIAS | _hip.EPI_GELU | _hip.EPI_OUT_BF16 | (_hip.EPI_LN_IN if fold else 0)
-        fc1_ms, fc1_n, peaks = 0.0, 0, None
+        recs, peaks = [], None
         if rank == 0 and not args.no_extra:
             was = net.use_graph
             net.use_graph = False
-            _hip.prof_gemm_begin(fc1_flags, Hd, D, 8192)
+            _hip.prof_all_begin(16384)
             solve(args.solver, gather=False)                  # rank 0 only: no collective in here
             torch.cuda.synchronize()
-            fc1_ms, fc1_n = _hip.prof_gemm_end()
+            recs = _hip.prof_all_end()
             net.use_graph = was
             peaks = _hip.prof_peaks()
         if world > 1:
@@ -310,23 +396,29 @@ def main():
             "mfma_util_whole_solve": fps * B * nfe * args.steps / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS,
         }
         line.update(extra)
-        if fc1_n > 0:
-            flops = 2.0 * M * Hd * D
-            avg_s = fc1_ms / fc1_n / 1e3
-            ach = flops / avg_s / 1e12
-            traffic = None
-            tp = os.path.join(ROOT, "profiles", "fc1_traffic.json")
-            if os.path.exists(tp) and args.model == "L_u" and B == 64:
-                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
-            line["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<256,256,2,4," + ("LN_IN|" if fold else "") + "BIAS|GELU|OUT_BF16> (fc1)",
-                                "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
-                                "launches": fc1_n, "avg_us": 1e6 * avg_s, "flops_per_launch": flops,
-                                "timing": "HIP events around every fc1 launch of one extra eager solve after the timed region"}
-            if peaks:
-                line["roofline"]["peak_measured"] = {"mfma_bf16_tflops": peaks[0], "hbm_copy_gbs": peaks[1],
-                                                     "frac_of_measured_mfma": ach / peaks[0],
-                                                     "how": "MFMA-only loop on every SIMD; 1 GiB device-to-device float4 copy (read + write bytes)"}
+        if recs:
+            all_rows = roofline_rows(recs, D)
+            line["roofline_all"] = all_rows
+            fc1 = [r for r in all_rows if r.get("epi_flags") == fc1_flags and r["role"] == "fc1"]
+            if fc1:
+                r = max(fc1, key=lambda q: q["launches"])
+                import ctypes
+                out = (ctypes.c_int * 8)()
+                _hip.check(_hip.lib().uspace_gemm_plan(r["M"], r["N"], out), "uspace_gemm_plan")
+                tile = f"{out[2]},{out[3]}"
+                waves = {(256, 256): "2,4", (192, 256): "2,4", (256, 128): "4,2", (128, 128): "2,2"}[(out[2], out[3])]
+                traffic, tnote = fc1_traffic(args.model, B, (out[2], out[3]))
+                line["roofline"] = {"bound": "mfma", "kernel": f"gemm_kernel<{tile},{waves}," + ("LN_IN|" if fold else "") + "BIAS|GELU|OUT_BF16> (fc1)",
+                                    "achieved": r["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": r["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_note": tnote,
+                                    "launches": r["launches"], "avg_us": r["avg_us"], "flops_per_launch": r["flops_per_launch"],
+                                    "timing": "HIP events around every fc1 launch of one extra eager solve after the timed region"}
+                if peaks:
+                    line["roofline"]["peak_measured"] = {
+                        "mfma_bf16_tflops": peaks[0], "hbm_copy_gbs": peaks[1], "shader_ghz_under_mfma_loop": peaks[2],
+                        "frac_of_measured_mfma": r["tflops"] / peaks[0],
+                        "how": "v_mfma_f32_32x32x16_bf16-only loop, one wave on every SIMD; the chip clocks to its power budget, so the "
+                               "measured rate = 2.5 PF x sustained clock / 2.4 GHz; 1 GiB device-to-device float4 copy (read + write bytes)"}
         if not args.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline(args.model, nfe)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define USPACE_ABI_VERSION 6
+#define USPACE_ABI_VERSION 7
 
 #define USPACE_OK 0
 #define USPACE_ERR_ARG (-1)         /* bad pointer / size / unsupported shape */
@@ -364,11 +364,18 @@ USPACE_API int uspace_quick_gelu_bf16(uint16_t* x, long n, uspace_stream_t strea
  * ------------------------------------------------------------------------------------- */
 USPACE_API int uspace_prof_gemm_begin(int epi_flags, int N, int K, int max_launches);
 USPACE_API int uspace_prof_gemm_end(double* total_ms, int* n_launches);
+/* The same around EVERY GEMM and attention launch (bench.py's roofline_all): _end() aggregates the recorded launches by
+ * (kind, flags, M, N, K) into keys[6 * i + {0: kind (0 GEMM, 1 attention), 1: epi_flags (attention: 1 = key scales),
+ * 2: M (attention: B * H), 3: N (attention: L), 4: K (attention: head dim), 5: launches}] and total_ms[i], i < *n_records <= max_records. */
+USPACE_API int uspace_prof_all_begin(int max_launches);
+USPACE_API int uspace_prof_all_end(int* keys, double* total_ms, int max_records, int* n_records);
 
 /* What this box reaches on the two rooflines (synchronous, self-timed with HIP events, own scratch; host pointers out):
  * dense bf16 MFMA rate of an MFMA-only loop on every SIMD (TFLOP/s), and a device-to-device float4 stream copy
  * (read + written bytes per second, GB/s) over `bytes` (>= 1 MiB) repeated `reps` times. */
 USPACE_API int uspace_prof_mfma_peak(int iters, double* tflops);
+/* ... and the shader clock the chip sustained under that load (GHz; s_memtime ticks of one workgroup / wall time) */
+USPACE_API int uspace_prof_mfma_peak_clock(int iters, double* tflops, double* shader_ghz);
 USPACE_API int uspace_prof_hbm_copy(size_t bytes, int reps, double* gb_per_s);
 
 #ifdef __cplusplus

@@ -1,0 +1,167 @@
+"""N > 1 readiness without multi-GPU hardware: the launch form of bench.py, and the two multi-process
+sampling loops of the reference (tools/utils_uvit.py:264-277 sample2dir, tools/utils_vis.py:168-241 the u-space sweep of BASELINE
+config 5) over DistAccelerator on world_size-2 gloo processes, with the hook keywords of config 5 (per-rank ``batch_id``,
+direction tables shared on disk, one DeltaCache per process)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+# ------------------------------------------------------------------------------------------- bench.py launch form
+def test_bench_relaunch_argv_and_world_size_check():
+    env = dict(os.environ, USPACE_BENCH_PRINT_RELAUNCH="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-400:]
+    argv = json.loads(out.stdout.strip().splitlines()[-1])
+    assert argv[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=2" in argv
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and int(argv[argv.index("--master-port") + 1]) > 0
+    i = argv.index(os.path.join(ROOT, "bench.py"))
+    assert argv[i + 1:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]          # the ranks run the same command line
+    # a rank started with the wrong world size stops before touching a device
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"),
+                         capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "--gpus 2 but WORLD_SIZE=3" in (bad.stderr + bad.stdout)
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.rank_env(8, dict(WORLD_SIZE="8", RANK="5", LOCAL_RANK="5")) == (8, 5, 5)
+    assert bench.rank_env(1, {}) == (1, 0, 0)
+    with pytest.raises(SystemExit):
+        bench.rank_env(2, dict(WORLD_SIZE="2", RANK="2", LOCAL_RANK="0"))
+
+
+# ------------------------------------------------------------------------------------------- the two sampling loops, 2 ranks
+L_TOK, D_EMB, N_ATTR = 5, 8, 40
+STEPS = [k / 10 for k in range(10)]                # t = 0.0 .. 0.9 (Euler-10 grid)
+
+
+def _hook_kwargs(root):
+    return dict(dissect_task="uspace_uvit", dissect_name="write_attr", edit_loc="mid", t_edit=0.4, ith_attr="31_39_20",
+                write_path_root=root, has_attr=False, dataset_name="celeba256", seed=3)
+
+
+def _write_tables(root):
+    rng = np.random.default_rng(11)
+    for k in range(0, 10):
+        np.save(os.path.join(root, f"delta_{k / 10:.2f}.npy"), (rng.standard_normal((N_ATTR, L_TOK, D_EMB)) * 0.1).astype(np.float32))
+
+
+class _StandInSolve:
+    """What a hooked solve does on the host side, with the network replaced by x <- 0.9 x + 0.01 (batch_id + 1): the product's
+    plan_uspace_hook / DeltaCache decide and fetch the edit of every step exactly as libs/uvit.py does around the mid block."""
+
+    def __init__(self):
+        from uspace_amd.libs.dissection import DeltaCache
+        self.cache = DeltaCache()
+        self.loads = 0
+        self.batch_ids = []
+
+    def __call__(self, input_z, write_scale, batch_id, **kwargs):
+        from uspace_amd.libs.dissection import plan_uspace_hook
+        self.batch_ids.append(batch_id)
+        x = input_z.reshape(input_z.shape[0], -1).clone()
+        for t in STEPS:
+            plan = plan_uspace_hook(f"{t:.2f}", dict(kwargs, write_scale=write_scale, batch_id=batch_id))
+            x = 0.9 * x + 0.01 * (batch_id + 1)
+            if plan is not None:
+                before = len(self.cache._store)
+                d = self.cache.get(plan.path, plan.ith, torch.device("cpu"), L_TOK * D_EMB)
+                self.loads += len(self.cache._store) - before
+                x = x + d[None] * plan.scale
+        return x.reshape(input_z.shape[0], 1, L_TOK, D_EMB)
+
+
+def _expected_rows(rank, world, mini, scales, root, rounds):
+    """Single-process recomputation of what rank `rank` contributes: [rounds][mini * n_scales, 1, L, D]."""
+    g = torch.Generator().manual_seed(100 + rank)
+    fn = _StandInSolve()
+    out = []
+    for b in range(rounds):
+        z = torch.randn(mini, 1, L_TOK, D_EMB, generator=g)
+        cols = [fn(input_z=z, write_scale=s, batch_id=b, **_hook_kwargs(root)) for s in scales]
+        out.append(torch.stack(cols, dim=1).reshape(-1, 1, L_TOK, D_EMB))
+    return out
+
+
+def _vis_worker(rank, world, port, root, outdir, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from uspace_amd.tools.utils_uvit import DistAccelerator, sample2dir
+    from uspace_amd.tools.utils_vis import sample_for_hspace_vis
+    acc = DistAccelerator()
+    assert acc.num_processes == world and acc.process_index == rank and acc.is_main_process == (rank == 0)
+    scales = [-1.0, 0.0, 2.0]
+    mini, n_samples = 2, 8                                           # 2 rounds of 2 x 2 latents
+    grids = []
+    fn = _StandInSolve()
+    written = sample_for_hspace_vis(acc, outdir, fn, z_shape=(1, L_TOK, D_EMB), device=torch.device("cpu"), n_samples=n_samples,
+                                    mini_batch_size=mini, write_scales=scales, generator=torch.Generator().manual_seed(100 + rank),
+                                    attr_name_fn=lambda ith, ds: f"attr{ith}", padding=0,
+                                    save_grid_fn=lambda grid, path: grids.append(grid.clone()), **_hook_kwargs(root))
+    ok = fn.batch_ids == [0, 0, 0, 1, 1, 1]                          # every rank numbers its rounds itself (batch_id of the reference loop)
+    ok = ok and fn.loads == 4                                        # t = 0.10 .. 0.40 edit ("0.00" never does): 4 tables, read once per process
+    if rank == 0:
+        ok = ok and len(written) == 2 and len(grids) == 2
+        exp = [_expected_rows(r, world, mini, scales, root, 2) for r in range(world)]
+        for b in range(2):
+            rows = torch.cat([exp[r][b] for r in range(world)])      # rank order, then (sample, scale) order inside a rank
+            n = rows.shape[0]
+            assert n == world * mini * len(scales)
+            got = grids[b]                                            # make_grid: nrow = len(scales), padding 0, 1 -> 3 channels
+            tiles = got[0].reshape(n // len(scales), L_TOK, len(scales), D_EMB).permute(0, 2, 1, 3).reshape(n, L_TOK, D_EMB)
+            ok = ok and torch.allclose(tiles, rows[:, 0], atol=0, rtol=0)
+    else:
+        ok = ok and written == []
+    # sample2dir: 7 samples, 2 per rank and round -> rounds of 4 and 3; the main process writes 0.png .. 6.png in rank order
+    saved = []
+    cnt = [0]
+
+    def sample_fn(n):
+        cnt[0] += 1
+        return torch.full((n, 1, 2, 2), float(10 * rank + cnt[0]))
+    nw = sample2dir(acc, os.path.join(outdir, "s2d"), 7, 2, sample_fn, save_fn=lambda s, f: saved.append((os.path.basename(f), float(s.mean()))))
+    if rank == 0:
+        ok = ok and nw == 7 and saved == [("0.png", 1.0), ("1.png", 1.0), ("2.png", 11.0), ("3.png", 11.0), ("4.png", 2.0), ("5.png", 2.0), ("6.png", 12.0)]
+    else:
+        ok = ok and nw == 0 and saved == []
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_uspace_sweep_and_sample2dir(tmp_path):
+    root = str(tmp_path / "tables")
+    os.makedirs(root)
+    _write_tables(root)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_vis_worker, args=(r, 2, port, root, str(tmp_path / "out"), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    got = dict(q.get(timeout=5) for _ in range(2))
+    assert got == {0: True, 1: True}

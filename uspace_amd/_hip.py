@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libuspace_hip.so")
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_OUT_BF16 = 1, 2, 4, 8, 16
 EPI_CEN_OUT, EPI_LN_IN = 32, 64          # uspace_gemm_bf16_ext only (LayerNorm folded through the GEMMs)
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _ERR = {-1: "USPACE_ERR_ARG", -2: "USPACE_ERR_LAUNCH", -3: "USPACE_ERR_WORKSPACE"}
 
@@ -115,7 +115,10 @@ SIGNATURES = {
     "uspace_quick_gelu_bf16": (_I, [_P, _L, _P]),
     "uspace_prof_gemm_begin": (_I, [_I, _I, _I, _I]),
     "uspace_prof_gemm_end": (_I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I)]),
+    "uspace_prof_all_begin": (_I, [_I]),
+    "uspace_prof_all_end": (_I, [ctypes.POINTER(_I), ctypes.POINTER(ctypes.c_double), _I, ctypes.POINTER(_I)]),
     "uspace_prof_mfma_peak": (_I, [_I, ctypes.POINTER(ctypes.c_double)]),
+    "uspace_prof_mfma_peak_clock": (_I, [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "uspace_prof_hbm_copy": (_I, [_SZ, _I, ctypes.POINTER(ctypes.c_double)]),
 }
 
@@ -284,11 +287,26 @@ def prof_gemm_begin(epi_flags, N, K, max_launches=8192):
 
 
 def prof_peaks(mfma_iters=20000, copy_bytes=1 << 30, copy_reps=10):
-    """(dense bf16 MFMA TFLOP/s of an MFMA-only loop, stream-copy GB/s read + write) measured on the current device."""
-    tf, gb = ctypes.c_double(0.0), ctypes.c_double(0.0)
-    check(lib().uspace_prof_mfma_peak(mfma_iters, ctypes.byref(tf)), "uspace_prof_mfma_peak")
+    """(dense bf16 MFMA TFLOP/s of a v_mfma_f32_32x32x16_bf16-only loop, stream-copy GB/s read + write, sustained shader
+    clock in GHz under the MFMA loop) measured on the current device."""
+    tf, gb, ghz = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+    check(lib().uspace_prof_mfma_peak_clock(mfma_iters, ctypes.byref(tf), ctypes.byref(ghz)), "uspace_prof_mfma_peak_clock")
     check(lib().uspace_prof_hbm_copy(copy_bytes, copy_reps, ctypes.byref(gb)), "uspace_prof_hbm_copy")
-    return tf.value, gb.value
+    return tf.value, gb.value, ghz.value
+
+
+def prof_all_begin(max_launches=16384):
+    check(lib().uspace_prof_all_begin(max_launches), "uspace_prof_all_begin")
+
+
+def prof_all_end(max_records=256):
+    """-> list of dicts(kind, flags, M, N, K, launches, total_ms), one per distinct (kind, flags, M, N, K)."""
+    keys = (ctypes.c_int * (6 * max_records))()
+    ms = (ctypes.c_double * max_records)()
+    n = ctypes.c_int(0)
+    check(lib().uspace_prof_all_end(keys, ms, max_records, ctypes.byref(n)), "uspace_prof_all_end")
+    return [dict(kind=keys[6 * i], flags=keys[6 * i + 1], M=keys[6 * i + 2], N=keys[6 * i + 3], K=keys[6 * i + 4],
+                 launches=keys[6 * i + 5], total_ms=ms[i]) for i in range(n.value)]
 
 
 def prof_gemm_end():

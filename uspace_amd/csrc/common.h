@@ -153,6 +153,12 @@ __device__ __forceinline__ void gelu_erf_batch(f32x4 (&v)[NV]) {
 
 static inline int us_cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Launch recorder (prof.hip; bench.py's roofline objects): HIP events on the launching stream around the launches of the
+// hot kernels.  us_rec_begin returns -1 unless a recording was started through the C-ABI (uspace_prof_*_begin).
+enum { US_REC_GEMM = 0, US_REC_ATTENTION = 1 };
+int us_rec_begin(int kind, int flags, int M, int N, int K, hipStream_t s);
+void us_rec_end(int idx, hipStream_t s);
+
 // Opt a kernel in to more than 64 KiB of dynamic LDS.  The attribute is per DEVICE: `done` (one per kernel, static at the
 // launch site) records the devices already served as a bit mask, so a process that drives several GPUs sets it on each
 // of them, and concurrent host threads at worst set it twice.  Devices >= 64 set it on every launch.

@@ -747,17 +747,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 2) ? 2 : 1) v
     }
 }
 
-// ---- optional launch recorder (bench.py's roofline line): HIP events around matching GEMM launches,
-// on the stream the kernel is launched on.  Off by default; the only global state in the library.
-struct Recorder {
-    bool on = false;
-    int flags = -1, N = 0, K = 0;
-    std::vector<hipEvent_t> ev;   // start/stop pairs
-    size_t used = 0;
-    size_t cap = 0;
-};
-Recorder g_rec;
-
 // Tiling plan: how many BM-row tile rows get their own workgroups, the remaining rows being cut into n_strip strips of 16
 // rows owned by that many tile rows.  Cost model: rounds of workgroups over the CUs; a strip owner does one more 16-row
 // MFMA tile (1/16 of a 256-row tile, 1/8 of a 128-row one), which costs its share of the work plus a tail.
@@ -797,15 +786,11 @@ int launch(const GemmArgs& a, hipStream_t s, int wg_per_round) {
     g.tiles_m = p.tiles_m;
     g.m_main = p.m_main;
     g.n_strip = p.n_strip;
-    const bool rec = g_rec.on && g_rec.flags == FLAGS && g_rec.N == g.N && g_rec.K == g.K && g_rec.used + 2 <= g_rec.cap;
-    if (rec) (void)hipEventRecord(g_rec.ev[g_rec.used], s);
+    const int rec = us_rec_begin(US_REC_GEMM, FLAGS, g.M, g.N, g.K, s);
     const dim3 grid(g.tiles_m * g.tiles_n), block(64 * WM * WN);
     if (p.n_strip > 0) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, FLAGS, true>), grid, block, 0, s, g);
     else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, FLAGS, false>), grid, block, 0, s, g);
-    if (rec) {
-        (void)hipEventRecord(g_rec.ev[g_rec.used + 1], s);
-        g_rec.used += 2;
-    }
+    us_rec_end(rec, s);
     US_CHECK_LAUNCH();
     return USPACE_OK;
 }
@@ -983,15 +968,11 @@ int dispatch_tile(const GemmArgs& a, hipStream_t s) {
         if (tc == TILE_SMALL && a.split_ws) {
             const int S = split_factor(us_cdiv(a.M, 128) * us_cdiv(a.N, 128), a.K);
             if (S > 1 && (size_t)S * a.M * a.N * 4 <= a.split_ws_bytes) {
-                const bool rec = g_rec.on && g_rec.flags == FLAGS && g_rec.N == a.N && g_rec.K == a.K && g_rec.used + 2 <= g_rec.cap;
-                if (rec) (void)hipEventRecord(g_rec.ev[g_rec.used], s);
+                const int rec = us_rec_begin(US_REC_GEMM, FLAGS, a.M, a.N, a.K, s);
                 const int rc = launch_split(a, s, S);
                 if (rc != USPACE_OK) return rc;
                 hipLaunchKernelGGL(splitk_finish_kernel, dim3(a.M), dim3(256), 0, s, a.split_ws, S, (long)a.M * a.N, a, FLAGS, us_cdiv(a.N, 128));
-                if (rec) {
-                    (void)hipEventRecord(g_rec.ev[g_rec.used + 1], s);
-                    g_rec.used += 2;
-                }
+                us_rec_end(rec, s);
                 US_CHECK_LAUNCH();
                 return USPACE_OK;
             }
@@ -1169,34 +1150,4 @@ extern "C" int uspace_gemm_slabs_bf16(const uint16_t* A, int lda, const uint16_t
     g.nk_split = 0; g.split_stride = 0; g.split_ws = nullptr; g.split_ws_bytes = 0;
     g.wide = wide_ok(g, epi_flags);
     return dispatch_flags(g, epi_flags, (hipStream_t)stream);
-}
-
-extern "C" int uspace_prof_gemm_begin(int epi_flags, int N, int K, int max_launches) {
-    if (max_launches <= 0) return USPACE_ERR_ARG;
-    while (g_rec.ev.size() < (size_t)max_launches * 2) {
-        hipEvent_t e;
-        if (hipEventCreate(&e) != hipSuccess) return USPACE_ERR_LAUNCH;
-        g_rec.ev.push_back(e);
-    }
-    g_rec.cap = (size_t)max_launches * 2;
-    g_rec.used = 0;
-    g_rec.flags = epi_flags; g_rec.N = N; g_rec.K = K;
-    g_rec.on = true;
-    return USPACE_OK;
-}
-
-extern "C" int uspace_prof_gemm_end(double* total_ms, int* n_launches) {
-    g_rec.on = false;
-    if (!total_ms || !n_launches) return USPACE_ERR_ARG;
-    double tot = 0.0;
-    for (size_t i = 0; i + 1 < g_rec.used; i += 2) {
-        if (hipEventSynchronize(g_rec.ev[i + 1]) != hipSuccess) return USPACE_ERR_LAUNCH;
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, g_rec.ev[i], g_rec.ev[i + 1]) != hipSuccess) return USPACE_ERR_LAUNCH;
-        tot += ms;
-    }
-    *total_ms = tot;
-    *n_launches = (int)(g_rec.used / 2);
-    g_rec.used = 0;
-    return USPACE_OK;
 }

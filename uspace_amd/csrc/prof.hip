@@ -1,13 +1,45 @@
 // Measurement aids (bench.py): what THIS box reaches on the two rooflines the kernels are priced against.
 //   uspace_prof_mfma_peak: dense bf16 MFMA issue rate -- every SIMD of every CU runs back-to-back v_mfma_f32_32x32x16_bf16 on
-//                          independent accumulators, nothing else (no LDS, no memory);
+//                          independent accumulators, nothing else (no LDS, no memory), one wave per SIMD;
 //   uspace_prof_hbm_copy : device-to-device float4 stream copy, read + write bytes per second.
 // Both are synchronous (they time themselves with HIP events on the NULL stream) and allocate their own scratch.
+#include <map>
+#include <tuple>
+#include <vector>
+
 #include "common.h"
 
 namespace {
 
-__global__ __launch_bounds__(256) void mfma_loop_kernel(float* out, int iters) {
+// ---- launch recorder: the only global state of the library; off unless a uspace_prof_*_begin() call switched it on
+struct RecEntry {
+    int kind, flags, M, N, K;
+};
+struct Recorder {
+    bool on = false;
+    bool filtered = false;          // uspace_prof_gemm_begin: GEMM launches whose (flags, N, K) match only
+    int f_flags = -1, f_N = 0, f_K = 0;
+    std::vector<hipEvent_t> ev;     // start / stop pairs
+    std::vector<RecEntry> what;
+    size_t used = 0, cap = 0;
+};
+Recorder g_rec;
+
+int rec_arm(int max_launches) {
+    if (max_launches <= 0) return USPACE_ERR_ARG;
+    while (g_rec.ev.size() < (size_t)max_launches * 2) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return USPACE_ERR_LAUNCH;
+        g_rec.ev.push_back(e);
+    }
+    g_rec.what.assign((size_t)max_launches, RecEntry{});
+    g_rec.cap = (size_t)max_launches;
+    g_rec.used = 0;
+    return USPACE_OK;
+}
+
+__global__ __launch_bounds__(256) void mfma_loop_kernel(float* out, int iters, unsigned long long* cycles) {
+    const unsigned long long c0 = __builtin_readcyclecounter();
     f32x16 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -25,6 +57,8 @@ __global__ __launch_bounds__(256) void mfma_loop_kernel(float* out, int iters) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
     }
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    if (cycles && blockIdx.x == 0 && threadIdx.x == 0) *cycles = c1 - c0;      // shader-clock ticks of one workgroup's loop
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -40,30 +74,113 @@ __global__ __launch_bounds__(256) void copy_kernel(const float4* __restrict__ sr
 
 }  // namespace
 
-extern "C" int uspace_prof_mfma_peak(int iters, double* tflops) {
+int us_rec_begin(int kind, int flags, int M, int N, int K, hipStream_t s) {
+    if (!g_rec.on || g_rec.used >= g_rec.cap) return -1;
+    if (g_rec.filtered && (kind != US_REC_GEMM || flags != g_rec.f_flags || N != g_rec.f_N || K != g_rec.f_K)) return -1;
+    const int idx = (int)g_rec.used++;
+    g_rec.what[idx] = RecEntry{kind, flags, M, N, K};
+    (void)hipEventRecord(g_rec.ev[2 * idx], s);
+    return idx;
+}
+
+void us_rec_end(int idx, hipStream_t s) {
+    if (idx >= 0) (void)hipEventRecord(g_rec.ev[2 * idx + 1], s);
+}
+
+extern "C" int uspace_prof_gemm_begin(int epi_flags, int N, int K, int max_launches) {
+    US_TRY(rec_arm(max_launches));
+    g_rec.filtered = true;
+    g_rec.f_flags = epi_flags; g_rec.f_N = N; g_rec.f_K = K;
+    g_rec.on = true;
+    return USPACE_OK;
+}
+
+extern "C" int uspace_prof_gemm_end(double* total_ms, int* n_launches) {
+    g_rec.on = false;
+    if (!total_ms || !n_launches) return USPACE_ERR_ARG;
+    double tot = 0.0;
+    for (size_t i = 0; i < g_rec.used; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_rec.ev[2 * i + 1]) != hipSuccess) return USPACE_ERR_LAUNCH;
+        if (hipEventElapsedTime(&ms, g_rec.ev[2 * i], g_rec.ev[2 * i + 1]) != hipSuccess) return USPACE_ERR_LAUNCH;
+        tot += ms;
+    }
+    *total_ms = tot;
+    *n_launches = (int)g_rec.used;
+    g_rec.used = 0;
+    return USPACE_OK;
+}
+
+extern "C" int uspace_prof_all_begin(int max_launches) {
+    US_TRY(rec_arm(max_launches));
+    g_rec.filtered = false;
+    g_rec.on = true;
+    return USPACE_OK;
+}
+
+extern "C" int uspace_prof_all_end(int* keys, double* total_ms, int max_records, int* n_records) {
+    g_rec.on = false;
+    if (!keys || !total_ms || !n_records || max_records <= 0) return USPACE_ERR_ARG;
+    std::map<std::tuple<int, int, int, int, int>, std::pair<int, double>> agg;
+    for (size_t i = 0; i < g_rec.used; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_rec.ev[2 * i + 1]) != hipSuccess) return USPACE_ERR_LAUNCH;
+        if (hipEventElapsedTime(&ms, g_rec.ev[2 * i], g_rec.ev[2 * i + 1]) != hipSuccess) return USPACE_ERR_LAUNCH;
+        const RecEntry& e = g_rec.what[i];
+        auto& slot = agg[std::make_tuple(e.kind, e.flags, e.M, e.N, e.K)];
+        slot.first += 1;
+        slot.second += ms;
+    }
+    g_rec.used = 0;
+    int n = 0;
+    for (const auto& kv : agg) {
+        if (n >= max_records) break;
+        int* k = keys + 6 * n;
+        k[0] = std::get<0>(kv.first); k[1] = std::get<1>(kv.first); k[2] = std::get<2>(kv.first);
+        k[3] = std::get<3>(kv.first); k[4] = std::get<4>(kv.first); k[5] = kv.second.first;
+        total_ms[n] = kv.second.second;
+        ++n;
+    }
+    *n_records = n;
+    return USPACE_OK;
+}
+
+extern "C" int uspace_prof_mfma_peak_clock(int iters, double* tflops, double* shader_ghz) {
     if (iters <= 0 || !tflops) return USPACE_ERR_ARG;
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return USPACE_ERR_LAUNCH;
-    const int blocks = prop.multiProcessorCount * 2;     // 8 waves per CU = 2 per SIMD
+    // one 4-wave workgroup per CU = one wave per SIMD: a lone wave issues v_mfma_f32_32x32x16_bf16 back to back at the pipe's
+    // rate (32.0 cycles each, tools/lab/overlap2_lab), and with a single round of workgroups one workgroup's tick count spans the launch
+    const int blocks = prop.multiProcessorCount;
     float* out = nullptr;
-    if (hipMalloc(&out, (size_t)blocks * 256 * sizeof(float)) != hipSuccess) return USPACE_ERR_LAUNCH;
+    if (hipMalloc(&out, (size_t)blocks * 256 * sizeof(float) + 8) != hipSuccess) return USPACE_ERR_LAUNCH;
+    unsigned long long* cyc = (unsigned long long*)(out + (size_t)blocks * 256);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL(mfma_loop_kernel, dim3(blocks), dim3(256), 0, 0, out, iters / 8 + 1);   // warm-up
+    hipLaunchKernelGGL(mfma_loop_kernel, dim3(blocks), dim3(256), 0, 0, out, iters / 8 + 1, (unsigned long long*)nullptr);   // warm-up
     (void)hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(mfma_loop_kernel, dim3(blocks), dim3(256), 0, 0, out, iters);
+    hipLaunchKernelGGL(mfma_loop_kernel, dim3(blocks), dim3(256), 0, 0, out, iters, cyc);
     (void)hipEventRecord(e1, 0);
     int rc = USPACE_OK;
     float ms = 0.f;
-    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || hipGetLastError() != hipSuccess) rc = USPACE_ERR_LAUNCH;
-    else *tflops = 2.0 * 32 * 32 * 16 * 32.0 * iters * 4.0 * blocks / (ms * 1e-3) / 1e12;   // 32 MFMAs per iteration per wave, 4 waves per block
+    unsigned long long hc = 0;
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || hipGetLastError() != hipSuccess ||
+        hipMemcpy(&hc, cyc, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = USPACE_ERR_LAUNCH;
+    else {
+        *tflops = 2.0 * 32 * 32 * 16 * 32.0 * iters * 4.0 * blocks / (ms * 1e-3) / 1e12;   // 32 MFMAs per iteration per wave, 4 waves per block
+        // every workgroup runs the same loop at the same time: one workgroup's tick count over the launch's wall time is the
+        // sustained shader clock under this (matrix-pipe-only) load
+        if (shader_ghz) *shader_ghz = (double)hc / (ms * 1e-3) / 1e9;
+    }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipFree(out);
     return rc;
 }
+
+extern "C" int uspace_prof_mfma_peak(int iters, double* tflops) { return uspace_prof_mfma_peak_clock(iters, tflops, nullptr); }
 
 extern "C" int uspace_prof_hbm_copy(size_t bytes, int reps, double* gb_per_s) {
     if (bytes < (1u << 20) || reps <= 0 || !gb_per_s) return USPACE_ERR_ARG;
