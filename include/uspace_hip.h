@@ -71,7 +71,7 @@ USPACE_API int uspace_gemm_bf16(const uint16_t* A, int lda, const uint16_t* A2, 
  * Producer of x (proj / fc2 / skip_linear, USPACE_EPI_CEN_OUT): besides its usual outputs writes out_cen[m, n] =
  *   bf16(v[m, n] - row_c[m]) -- row_c is any per-row constant close to the row mean, so the rounding acts on centred
  *   values exactly as it does on LayerNorm's output today -- and part_out[m][tile][2] = (sum, sum of squares) of
- *   v - row_c over each N tile (uspace_gemm_part_slots(M, N) tiles per row; fixed summation order, no atomics).
+ *   v - row_c over each N tile (uspace_gemm_part_slots_k(M, N, K) tiles per row; fixed summation order, no atomics).
  * Consumer (qkv / fc1, USPACE_EPI_LN_IN): A = out_cen, W = bf16(W * gamma), bias = b + W beta, colsum[n] = sum_k of the
  *   bf16 W rows; from part_in it derives d = mean(v - row_c), rstd = 1/sqrt(var + eps) (norm_dim = row length) and
  *   applies y = rstd * (acc - d * colsum) + bias before the rest of the epilogue; with c_out it also publishes
@@ -80,7 +80,7 @@ typedef struct uspace_gemm_ext {
     const float* row_c;     /* [M]   CEN_OUT: centring constants; LN_IN: the ones its producer used (only with c_out) */
     uint16_t* out_cen;      /* [M, ld_cen] bf16 */
     int ld_cen;
-    float* part_out;        /* [M][uspace_gemm_part_slots(M, N)][2] */
+    float* part_out;        /* [M][uspace_gemm_part_slots_k(M, N, K)][2] */
     const float* part_in;   /* [M][np_in][2] */
     int np_in;              /* <= 8 */
     const float* colsum;    /* [N] */
@@ -113,7 +113,9 @@ USPACE_API int uspace_center_rows(const float* x, uint16_t* xc, float* c, float*
 USPACE_API int uspace_uvit_set_ln_fold(int mode);
 USPACE_API int uspace_uvit_get_ln_fold(void);
 /* number of N tiles (= partial-sum slots per row) a CEN_OUT launch with this [M, N] output uses */
-USPACE_API int uspace_gemm_part_slots(int M, int N);
+USPACE_API int uspace_gemm_part_slots(int M, int N);       /* the largest count over K: size part_out / check np_in <= 8 with it */
+/* ... of the producer GEMM with this K (launches with few tiles and K < 2048 use 64-wide tiles: more slots) */
+USPACE_API int uspace_gemm_part_slots_k(int M, int N, int K);
 
 /* Which tile configuration uspace_gemm_bf16 uses for an [M, N] output (host-side planning, no GPU work):
  * 0 = 256x256 tiles, 1 = 192x256, 2 = 128x128, 3 = rows [0, *split_rows) as 256x256 and the rest as 128x128,

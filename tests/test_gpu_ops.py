@@ -462,8 +462,8 @@ def test_layernorm_folded_through_gemms(hip, M, D, Kp, N2):
     # centring constants: the row mean of a *previous* state (here: of R alone) -- close to, not equal to, the new mean
     c = R.mean(axis=1).astype(np.float32)
     lib = hip.lib()
-    slots = lib.uspace_gemm_part_slots(M, D)
-    assert slots in (-(-D // 256), -(-D // 128))
+    slots = lib.uspace_gemm_part_slots_k(M, D, Kp)          # of THIS producer (64-wide tiles for few-tile, short-K launches)
+    assert slots in (-(-D // 256), -(-D // 128), -(-D // 64)) and slots <= lib.uspace_gemm_part_slots(M, D)
     dA, dW, db = to_dev(A, torch.bfloat16), to_dev(W, torch.bfloat16), to_dev(b)
     x = to_dev(R).clone()
     xc = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")

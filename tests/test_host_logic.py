@@ -587,7 +587,13 @@ def test_gemm_plans_on_random_shapes():
         # producers of LayerNorm partial sums: 128-wide slots for the 128x128 form, and for the 256x128 form only while that makes at
         # most 8 of them (the consumers read up to 8): wider N falls back to 256-wide tiles
         narrow = choice == 2 or (choice == 4 and -(-N // 128) <= 8)
-        assert L.uspace_gemm_part_slots(M, N) == (-(-N // 128) if narrow else -(-N // 256))
+        # ... and 64-wide slots where the 128x128 tiling would fill 160 workgroups or fewer, the K loop is short (< 2048) and
+        # that makes at most 8 slots (uspace_gemm_part_slots = the count for short K loops = the largest over K)
+        tiny = choice == 2 and -(-M // 128) * -(-N // 128) <= 160 and -(-N // 64) <= 8
+        for Kq, t in ((K, tiny and K < 2048), (64, tiny)):
+            got = L.uspace_gemm_part_slots_k(M, N, Kq)
+            assert got == (-(-N // 64) if t else -(-N // 128) if narrow else -(-N // 256)), (M, N, Kq)
+        assert L.uspace_gemm_part_slots(M, N) == L.uspace_gemm_part_slots_k(M, N, 64)
         ws = L.uspace_gemm_split_ws_bytes(M, N, K)
         if ws:
             S = ws // (M * N * 4)

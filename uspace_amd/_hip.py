@@ -63,6 +63,7 @@ SIGNATURES = {
     "uspace_gemm_bf16_ext": (_I, [_P, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I,
                                   ctypes.POINTER(GemmExt), _P]),
     "uspace_gemm_part_slots": (_I, [_I, _I]),
+    "uspace_gemm_part_slots_k": (_I, [_I, _I, _I]),
     "uspace_gemm_split_ws_bytes": (_SZ, [_I, _I, _I]),
     "uspace_fold_layernorm": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "uspace_center_rows": (_I, [_P, _P, _P, _P, _I, _I, _P]),

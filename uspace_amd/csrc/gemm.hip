@@ -607,9 +607,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 2) ? 2 : 1) v
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4]), "+v"(rv[5]), "+v"(rv[6]), "+v"(rv[7]), "+v"(rv[8]));
         else if constexpr (TM == 6)
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4]), "+v"(rv[5]), "+v"(rv[6]));
-        else
+        else if constexpr (TM == 4)
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4]));
-        static_assert(!ROWV || TM == 8 || TM == 6 || TM == 4, "row-value fetch is written for TM = 8 / 6 / 4");
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]));
+        static_assert(!ROWV || TM == 8 || TM == 6 || TM == 4 || TM == 2, "row-value fetch is written for TM = 8 / 6 / 4 / 2");
     }
     auto row_begin = [&](int ri) {            // ri: index into rv (sub-tile i, or TM for the strip row)
         if constexpr (LN_IN) {
@@ -897,7 +899,7 @@ inline GemmArgs row_slice(const GemmArgs& a, int m_lo, int m_hi) {
     return g;
 }
 
-enum TileChoice { TILE_BIG = 0, TILE_MID = 1, TILE_SMALL = 2, TILE_SPLIT = 3, TILE_TALL = 4 };
+enum TileChoice { TILE_BIG = 0, TILE_MID = 1, TILE_SMALL = 2, TILE_SPLIT = 3, TILE_TALL = 4, TILE_TINY = 5 };
 
 // Four tile configurations, chosen by a round-count cost model (unit: one round of 256x256 tiles):
 //   256x256, 8 waves (2x4), ~130 KiB LDS, 1 workgroup/CU     cost 1.00 per round of 256 tiles
@@ -950,6 +952,18 @@ TileChoice choose_tile(int M, int N, int* split_rows) {
     return best == cost_mid ? TILE_MID : TILE_SMALL;
 }
 
+// Fifth form, 64x64 tiles (4 waves, 2 x 2, 36 KiB of LDS): launches whose 128x128 tiling would leave a third or more of the
+// CUs without a workgroup, with a K loop short enough that latency -- not staging traffic -- is the cost (K < 2048; longer
+// K loops keep the K-split form of the 128x128 tiles).  Four times the workgroups, a quarter of the LDS-DMA issue per wave
+// and K tile: U-ViT-S at 4 x 257 rows proj 12.4 -> 7.7 us, qkv 9.7 -> 8.0, fc1 10.8 -> 9.4, skip_linear 15.8 (split) -> 11.5
+// (rocprofv3 kernel trace, `profiles/r03_small_m.md`).  Producers of LayerNorm partial sums take it only while N / 64 <= 8.
+inline TileChoice refine_small(TileChoice tc, int M, int N, int K, bool producer) {
+    if (tc != TILE_SMALL || K >= 2048) return tc;
+    if ((long)us_cdiv(M, 128) * us_cdiv(N, 128) > 160) return tc;
+    if (producer && us_cdiv(N, 64) > 8) return tc;
+    return TILE_TINY;
+}
+
 // Producers of folded-LayerNorm partial sums (CEN_OUT) write one (sum, sum of squares) pair per row and N tile, and the
 // consumers read at most 8 of them: one partial-sum stride per launch (no split form), and no 128-wide tiles when that
 // would make more than 8 slots (embed_dim > 1024: the 256-wide form halves the slot count, as before the 256x128 form existed)
@@ -964,6 +978,7 @@ int dispatch_tile(const GemmArgs& a, hipStream_t s) {
     int m1 = 0;
     TileChoice tc = choose_tile(a.M, a.N, &m1);
     if constexpr ((FLAGS & USPACE_EPI_CEN_OUT) != 0) tc = producer_tile(tc, a.N);
+    tc = refine_small(tc, a.M, a.N, a.K, (FLAGS & USPACE_EPI_CEN_OUT) != 0);
     if constexpr ((FLAGS & (USPACE_EPI_LN_IN | USPACE_EPI_GELU)) == 0) {
         if (tc == TILE_SMALL && a.split_ws) {
             const int S = split_factor(us_cdiv(a.M, 128) * us_cdiv(a.N, 128), a.K);
@@ -987,6 +1002,7 @@ int dispatch_tile(const GemmArgs& a, hipStream_t s) {
             if (rc != USPACE_OK) return rc;
             return launch<128, 128, 2, 2, FLAGS>(row_slice(a, m1, a.M), s, 512);
         }
+        case TILE_TINY: return launch<64, 64, 2, 2, FLAGS>(a, s, 1024);
         default: return launch<128, 128, 2, 2, FLAGS>(a, s, 512);
     }
 }
@@ -1022,12 +1038,15 @@ int wide_ok(const GemmArgs& g, int epi_flags) {
 
 }  // namespace
 
-extern "C" int uspace_gemm_part_slots(int M, int N) {
-    if (M <= 0 || N <= 0) return USPACE_ERR_ARG;
+extern "C" int uspace_gemm_part_slots_k(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return USPACE_ERR_ARG;
     int m1 = 0;
-    const TileChoice tc = producer_tile(choose_tile(M, N, &m1), N);
-    return us_cdiv(N, (tc == TILE_SMALL || tc == TILE_TALL) ? 128 : 256);
+    const TileChoice tc = refine_small(producer_tile(choose_tile(M, N, &m1), N), M, N, K, true);
+    return us_cdiv(N, tc == TILE_TINY ? 64 : (tc == TILE_SMALL || tc == TILE_TALL) ? 128 : 256);
 }
+
+// the largest slot count any producer of [M, N] rows writes (short K loops may take the 64-wide form)
+extern "C" int uspace_gemm_part_slots(int M, int N) { return uspace_gemm_part_slots_k(M, N, 64); }
 
 extern "C" size_t uspace_gemm_split_ws_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0 || K % BK) return 0;

@@ -138,7 +138,7 @@ Workspace plan_workspace(const uspace_uvit_config& c, const Model& m, int B) {
     w.ctx_f32 = take(c.clip_dim > 0 ? (size_t)B * c.n_extra * D * 4 : 0);
     w.head = take((size_t)B * c.in_chans * c.img_size * c.img_size * 4);
     w.xc = take(M * D * 2);                          // LayerNorm folding: centred bf16 copy of the residual stream
-    w.part = take(M * (size_t)us_cdiv((int)D, 128) * 2 * 4);   // per-row partial sums, one slot per producer N tile
+    w.part = take(M * (size_t)us_cdiv((int)D, 64) * 2 * 4);    // per-row partial sums, one slot per producer N tile (64 columns at the least)
     w.cbuf = take(M * 4);                            // per-row centring constants (row means at the last norm)
     // fp32 partial sums of the K-split form the GEMM uses for small batches (proj, skip_linear, fc2: N = D)
     w.splitk_bytes = std::max(std::max(uspace_gemm_split_ws_bytes((int)M, (int)D, (int)D), uspace_gemm_split_ws_bytes((int)M, (int)D, 2 * (int)D)),
@@ -289,8 +289,10 @@ extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* bl
         // read xc with gamma-folded weights and finish the normalisation in their epilogues.  No LayerNorm launch
         // except the first centring pass; the residual stream x itself is unchanged (fp32).
         constexpr int C_ = USPACE_EPI_CEN_OUT, L_ = USPACE_EPI_LN_IN;
-        const int slots = uspace_gemm_part_slots(M, D);
-        if (slots <= 0) return USPACE_ERR_ARG;
+        // partial-sum slots per row of each producer (the 64-wide tile form of short-K launches writes more of them)
+        const int slots_skip = uspace_gemm_part_slots_k(M, D, 2 * D), slots_proj = uspace_gemm_part_slots_k(M, D, D),
+                  slots_fc2 = uspace_gemm_part_slots_k(M, D, Hd);
+        if (slots_skip <= 0 || slots_proj <= 0 || slots_fc2 <= 0) return USPACE_ERR_ARG;
         auto PFx = [&](int idx) { return (const float*)(wb + m.lay.p[idx].offset); };
         US_TRY(uspace_center_rows(x, xc, cbuf, part, M, D, stream));
         int np = 1;                                   // partial-sum slots of whoever wrote xc last
@@ -304,7 +306,7 @@ extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* bl
                 const uint16_t* skip = skips + (size_t)(m.nblocks - 1 - i) * MD;
                 US_TRY(uspace_gemm_bf16_ext(xb, D, skip, D, D, PH(b.skip_w), 2 * D, M, D, 2 * D, C_ | B_ | F_, PF(b.skip_b),
                                             nullptr, 0, x, D, nullptr, 0, &prod, stream));
-                np = slots;
+                np = slots_skip;
             }
             uspace_gemm_ext cons{};
             cons.row_c = cbuf; cons.c_out = cbuf; cons.part_in = part; cons.np_in = np; cons.norm_dim = D; cons.eps = 1e-5f;
@@ -315,7 +317,7 @@ extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* bl
             US_TRY(uspace_attention_bf16(qkv, ks, h, B, L, H, stream));
             US_TRY(uspace_gemm_bf16_ext(h, D, nullptr, 0, D, PH(b.projw), D, M, D, D, C_ | B_ | R_ | F_, PF(b.projb), x, D, x, D,
                                         nullptr, 0, &prod, stream));
-            np = slots;
+            np = slots_proj;
             cons.np_in = np;
             cons.colsum = PFx(b.fc1_cs);
             US_TRY(uspace_gemm_bf16_ext(xc, D, nullptr, 0, D, PH(b.fc1_f), D, M, Hd, D, L_ | B_ | G_ | H_, PFx(b.fc1_fb), nullptr, 0,
@@ -324,6 +326,7 @@ extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* bl
                 // the next block starts with a norm: centred copy + partials, plus the raw bf16 skip
                 US_TRY(uspace_gemm_bf16_ext(f, Hd, nullptr, 0, Hd, PH(b.fc2w), Hd, M, D, Hd, C_ | B_ | R_ | F_ | H_, PF(b.fc2b), x, D,
                                             x, D, skips + (size_t)i * MD, D, &prod, stream));
+                np = slots_fc2;
             } else {
                 // mid / out blocks: the next consumer is skip_linear (raw bf16 xb) or the head (its own norm)
                 uint16_t* copy = is_last ? nullptr : xb;
