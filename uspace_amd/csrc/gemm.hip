@@ -244,32 +244,37 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 2) ? 2 : 1) v
     };
     const int kt0 = NST > 2 ? (int)blockIdx.y * g.nk_split : 0;   // ring form: this workgroup's K range starts here
     float* const out_f32 = NST > 2 ? g.out_f32 + (size_t)blockIdx.y * g.split_stride : g.out_f32;
+    // LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... offen lds): the descriptor is built from the wave-uniform
+    // base of this K tile, the per-lane part is ONE 32-bit VGPR offset per instruction, M0 carries the LDS address.  (The flat
+    // form global_load_lds needed a 64-bit VALU add into the same address register pair before every instruction -- the zero
+    // extension of the offsets was hoisted out of the loop, so the scalar-base addressing mode never matched -- and each add had to
+    // wait for the previous instruction to have read that pair: 80-130 cycles per DMA instruction, `profiles/r03_gemm_ablation.md`.)
+#ifndef USPACE_DMA_FLAT
+#define USPACE_DMA_FLAT 0       /* 1: the round-2 flat global_load_lds form (A/B measurements) */
+#endif
+    auto dma16 = [&](const char* ubase, const __amdgpu_buffer_rsrc_t& rs, uint32_t voff, char* lds) {
+        if constexpr (USPACE_DMA_FLAT != 0)
+            __builtin_amdgcn_global_load_lds((const US_GLB void*)(ubase + voff), (US_LDS void*)lds, 16, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (US_LDS void*)lds, 16, voff, 0, 0, 0);
+    };
     auto stage_a = [&](int kt, int buf) {
         const int k0 = (kt + kt0) * BK;
         char* base = smem + buf * STAGE_BYTES;
         const char* abase = a_base(k0);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)abase, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < ISSUES_A; ++i) {
-            __builtin_amdgcn_global_load_lds((const US_GLB void*)(abase + a_off[i]),
-                                             (US_LDS void*)(base + i * ROWS_PER_ISSUE * ROW_BYTES + wave_lds_off),
-                                             16, 0, 0);
-        }
+        for (int i = 0; i < ISSUES_A; ++i) dma16(abase, rs, a_off[i], base + i * ROWS_PER_ISSUE * ROW_BYTES + wave_lds_off);
         if constexpr (XTRA) {
-            if (has_x && wave < 2)
-                __builtin_amdgcn_global_load_lds((const US_GLB void*)(abase + x_off),
-                                                 (US_LDS void*)(base + TILE_A_BYTES + TILE_W_BYTES + wave_lds_off),
-                                                 16, 0, 0);
+            if (has_x && wave < 2) dma16(abase, rs, x_off, base + TILE_A_BYTES + TILE_W_BYTES + wave_lds_off);
         }
     };
     auto stage_w = [&](int kt, int buf) {
         const char* wbase = (const char*)(gW + (kt + kt0) * BK);
         char* base = smem + buf * STAGE_BYTES + TILE_A_BYTES;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < ISSUES_W; ++i) {
-            __builtin_amdgcn_global_load_lds((const US_GLB void*)(wbase + w_off[i]),
-                                             (US_LDS void*)(base + i * ROWS_PER_ISSUE * ROW_BYTES + wave_lds_off),
-                                             16, 0, 0);
-        }
+        for (int i = 0; i < ISSUES_W; ++i) dma16(wbase, rs, w_off[i], base + i * ROWS_PER_ISSUE * ROW_BYTES + wave_lds_off);
     };
 
     const int fr = lane & 15;   // fragment row (m for activations, n for weights)
@@ -840,8 +845,18 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* ws, int
     const float rc = (flags & USPACE_EPI_CEN_OUT) ? g.row_c[m] : 0.f;
     float ps1 = 0.f, ps2 = 0.f;
     for (int n = tid * 4; n < g.N; n += 256 * 4) {
-        f32x4 v = *(const f32x4*)(ws + (size_t)m * g.N + n);
-        for (int sp = 1; sp < S; ++sp) v += *(const f32x4*)(ws + sp * stride + (size_t)m * g.N + n);
+        // all S (<= 8) partial sums are requested before the first add (a runtime-trip-count loop of load + add made S dependent
+        // trips to L2 of it), then added in split order
+        // (loads are unconditional -- slots >= S re-read slot 0 -- so the compiler does not branch around each of them)
+        f32x4 pv[8];
+#pragma unroll
+        for (int sp = 0; sp < 8; ++sp) pv[sp] = *(const f32x4*)(ws + (sp < S ? sp : 0) * stride + (size_t)m * g.N + n);
+        f32x4 v = pv[0];
+#pragma unroll
+        for (int sp = 1; sp < 8; ++sp) {
+            const f32x4 w = v + pv[sp];
+            v = sp < S ? w : v;
+        }
         if (flags & USPACE_EPI_RESIDUAL) v += *(const f32x4*)(g.resid + (size_t)m * g.ld_resid + n);
         if (flags & USPACE_EPI_BIAS) v += *(const f32x4*)(g.bias + n);
         if (flags & USPACE_EPI_OUT_F32) *(f32x4*)(g.out_f32 + (size_t)m * g.ld_f32 + n) = v;
@@ -956,7 +971,7 @@ TileChoice choose_tile(int M, int N, int* split_rows) {
 // CUs without a workgroup, with a K loop short enough that latency -- not staging traffic -- is the cost (K < 2048; longer
 // K loops keep the K-split form of the 128x128 tiles).  Four times the workgroups, a quarter of the LDS-DMA issue per wave
 // and K tile: U-ViT-S at 4 x 257 rows proj 12.4 -> 7.7 us, qkv 9.7 -> 8.0, fc1 10.8 -> 9.4, skip_linear 15.8 (split) -> 11.5
-// (rocprofv3 kernel trace, `profiles/r03_small_m.md`).  Producers of LayerNorm partial sums take it only while N / 64 <= 8.
+// (rocprofv3 kernel trace, `profiles/r03_gemm_ablation.md` section 7).  Producers of LayerNorm partial sums take it only while N / 64 <= 8.
 inline TileChoice refine_small(TileChoice tc, int M, int N, int K, bool producer) {
     if (tc != TILE_SMALL || K >= 2048) return tc;
     if ((long)us_cdiv(M, 128) * us_cdiv(N, 128) > 160) return tc;
