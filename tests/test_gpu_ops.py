@@ -502,3 +502,136 @@ def test_layernorm_folded_through_gemms(hip, M, D, Kp, N2):
     # the plain entry point refuses the extended flags
     assert lib.uspace_gemm_bf16(hip.ptr(xc), D, None, 0, D, hip.ptr(dW2), D, M, N2, D, hip.EPI_OUT_BF16 | 64, None, None, 0,
                                 None, 0, hip.ptr(y), N2, hip.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize("M,N,K,kind", [
+    (4 * 257, 1536, 512, "ln_in"),          # U-ViT-S qkv at batch 4 (BASELINE config 1): consumer of the folded LayerNorm
+    (4 * 257, 2048, 512, "bias_gelu_bf16"),  # fc1 shape
+    (4 * 257, 512, 512, "producer"),        # proj: residual in place + centred copy + 8 partial-sum slots of 64 columns
+    (4 * 257, 512, 1024, "producer_2slab"),  # skip_linear: two K slabs, producer
+    (1030, 260, 192, "bias_resid_f32_bf16"),  # ragged rows and columns
+    (70, 64, 64, "f32"),                    # one tile row and a 6-row strip
+])
+def test_gemm_64x64_tile_form(hip, M, N, K, kind):
+    """Launches whose 128x128 tiling would fill 160 workgroups or fewer and whose K is below 2048 run as 64x64 tiles (round 3,
+    `refine_small` in gemm.hip): every epilogue family at the U-ViT-S batch-4 shapes against the oracle (libs/timm.py:106-112,
+    libs/uvit.py:135-161), with the partial-sum slot count (64-wide) as the witness that this form is the one that ran."""
+    import ctypes
+    lib = hip.lib()
+    assert -(-M // 128) * -(-N // 128) <= 160 and K < 2048
+    rng = np.random.default_rng(M * 7 + N + K)
+    A = bf16_round(_rand(rng, M, K))
+    W = bf16_round(_rand(rng, N, K) * 0.1)
+    b = _rand(rng, N)
+    R = (_rand(rng, M, N) + _rand(rng, M, 1)).astype(np.float32)
+    dA, dW, db = to_dev(A, torch.bfloat16), to_dev(W, torch.bfloat16), to_dev(b)
+    if kind.startswith("producer"):
+        slots = lib.uspace_gemm_part_slots_k(M, N, K)
+        assert slots == -(-N // 64) and lib.uspace_gemm_part_slots_k(M, N, 4096) == -(-N // 128)
+        c = R.mean(axis=1).astype(np.float32)
+        ref = C.linear(A, W, b) + R
+        x = to_dev(R).clone()
+        xc = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        part = torch.full((M, slots, 2), float("nan"), device="cuda")
+        dc = to_dev(c)
+        ext = hip.GemmExt(hip.ptr(dc).value, hip.ptr(xc).value, N, hip.ptr(part).value, None, 0, None, None, N, 1e-5)
+        flags = hip.EPI_BIAS | hip.EPI_RESIDUAL | hip.EPI_OUT_F32 | 32
+        if kind == "producer_2slab":
+            K1 = K // 2
+            a1, a2 = to_dev(np.ascontiguousarray(A[:, :K1]), torch.bfloat16), to_dev(np.ascontiguousarray(A[:, K1:]), torch.bfloat16)
+            rc = lib.uspace_gemm_bf16_ext(hip.ptr(a1), K1, hip.ptr(a2), K1, K1, hip.ptr(dW), K, M, N, K, flags, hip.ptr(db), hip.ptr(x), N,
+                                          hip.ptr(x), N, None, 0, ctypes.byref(ext), hip.stream_ptr())
+        else:
+            rc = lib.uspace_gemm_bf16_ext(hip.ptr(dA), K, None, 0, K, hip.ptr(dW), K, M, N, K, flags, hip.ptr(db), hip.ptr(x), N,
+                                          hip.ptr(x), N, None, 0, ctypes.byref(ext), hip.stream_ptr())
+        assert rc == 0
+        xg = x.cpu().numpy()
+        np.testing.assert_allclose(xg, ref, rtol=1e-3, atol=2e-3)
+        assert torch.equal(xc, (x - dc[:, None]).to(torch.bfloat16))
+        pg = part.cpu().numpy().astype(np.float64)
+        assert np.isfinite(pg).all()
+        cen = xg.astype(np.float64) - c[:, None]
+        np.testing.assert_allclose(pg[:, :, 0].sum(1), cen.sum(1), rtol=1e-4, atol=2e-2)
+        np.testing.assert_allclose(pg[:, :, 1].sum(1), (cen ** 2).sum(1), rtol=1e-4)
+        # each slot is the sum over ITS 64 columns
+        np.testing.assert_allclose(pg[:, 1, 0], cen[:, 64:128].sum(1), rtol=1e-4, atol=2e-2)
+        return
+    if kind == "ln_in":
+        D = K
+        x = (_rand(rng, M, D) * 1.5 + _rand(rng, M, 1) * 2.0).astype(np.float32)
+        gam, bet = (_rand(rng, D) * 0.2 + 1.0).astype(np.float32), _rand(rng, D, scale=0.1)
+        W2 = (_rand(rng, N, D) * 0.05).astype(np.float32)
+        y_ref = C.linear(C.layernorm(x, gam, bet, eps=1e-5), W2, b)
+        c = (x.mean(axis=1) + 0.1).astype(np.float32)
+        xc_np = bf16_round(x - c[:, None])
+        cen = (x - c[:, None]).astype(np.float64)
+        part = np.zeros((M, 8, 2), np.float32)
+        for q in range(8):
+            part[:, q, 0] = cen[:, q * 64:(q + 1) * 64].sum(1)
+            part[:, q, 1] = (cen[:, q * 64:(q + 1) * 64] ** 2).sum(1)
+        W2g = bf16_round(W2 * gam[None, :])
+        bias2 = (b + W2 @ bet).astype(np.float32)
+        colsum = W2g.sum(axis=1).astype(np.float32)
+        y = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        cout = torch.empty(M, device="cuda")
+        dxc, dW2, dbias2, dcs, dc, dpart = (to_dev(xc_np, torch.bfloat16), to_dev(W2g, torch.bfloat16), to_dev(bias2), to_dev(colsum),
+                                            to_dev(c), to_dev(part))
+        ext2 = hip.GemmExt(hip.ptr(dc).value, None, 0, None, hip.ptr(dpart).value, 8, hip.ptr(dcs).value, hip.ptr(cout).value, D, 1e-5)
+        rc = lib.uspace_gemm_bf16_ext(hip.ptr(dxc), D, None, 0, D, hip.ptr(dW2), D, M, N, D, hip.EPI_BIAS | hip.EPI_OUT_BF16 | 64,
+                                      hip.ptr(dbias2), None, 0, None, 0, hip.ptr(y), N, ctypes.byref(ext2), hip.stream_ptr())
+        assert rc == 0
+        assert rel_l2(y.float().cpu().numpy(), y_ref) < 4e-3
+        np.testing.assert_allclose(cout.cpu().numpy(), x.mean(axis=1), rtol=1e-4, atol=1e-4)
+        return
+    ref = C.linear(A, W, b if "bias" in kind else None)
+    if "gelu" in kind:
+        ref = C.gelu(ref)
+    if "resid" in kind:
+        ref = ref + R
+    x = to_dev(R).clone() if "resid" in kind else torch.full((M, N), float("nan"), device="cuda")
+    xb = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    hip.gemm(dA, dW, bias=db if "bias" in kind else None, resid=x if "resid" in kind else None, gelu="gelu" in kind,
+             out_f32=x if "f32" in kind else None, out_bf16=xb if "bf16" in kind else None)
+    if "f32" in kind:
+        got = x.cpu().numpy()
+        assert rel_l2(got, ref) < 1e-5
+        np.testing.assert_allclose(got, ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
+    if "bf16" in kind:
+        gotb = xb.float().cpu().numpy()
+        assert (np.abs(gotb - ref) <= BF16_EPS * np.abs(ref) * 1.01 + 1e-3 * np.abs(ref).max()).all()
+
+
+def test_launch_recorder_reports_every_gemm_and_attention_launch(hip):
+    """uspace_prof_all_begin / _end (bench.py's roofline_all): launches are aggregated by (kind, flags, M, N, K) with plausible
+    durations, nothing is recorded outside a begin / end pair, and the filtered recorder (uspace_prof_gemm_begin) still sees
+    only its own key."""
+    rng = np.random.default_rng(3)
+    M, N, K = 515, 256, 128
+    dA, dW = to_dev(bf16_round(_rand(rng, M, K)), torch.bfloat16), to_dev(bf16_round(_rand(rng, N, K)), torch.bfloat16)
+    o1 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    o2 = torch.empty(M, N, device="cuda")
+    B, L, H = 2, 257, 4
+    qkv = torch.randn(B * L, 3 * H * 64, device="cuda").to(torch.bfloat16)
+    hip.gemm(dA, dW, out_bf16=o1)                              # not recorded
+    hip.prof_all_begin(64)
+    for _ in range(3):
+        hip.gemm(dA, dW, out_bf16=o1)
+    for _ in range(2):
+        hip.gemm(dA, dW, out_f32=o2)
+    hip.attention(qkv, B, L, H)
+    torch.cuda.synchronize()
+    recs = hip.prof_all_end()
+    hip.gemm(dA, dW, out_bf16=o1)                              # not recorded either
+    assert hip.prof_all_end() == []
+    by = {(r["kind"], r["flags"], r["M"], r["N"], r["K"]): r for r in recs}
+    assert by[(0, hip.EPI_OUT_BF16, M, N, K)]["launches"] == 3 and by[(0, hip.EPI_OUT_F32, M, N, K)]["launches"] == 2
+    assert by[(1, 0, B * H, L, 64)]["launches"] == 1
+    assert all(0.0 < r["total_ms"] < 50.0 for r in recs) and len(recs) == 3
+    hip.prof_gemm_begin(hip.EPI_OUT_F32, N, K, 16)
+    hip.gemm(dA, dW, out_bf16=o1)
+    hip.gemm(dA, dW, out_f32=o2)
+    torch.cuda.synchronize()
+    ms, n = hip.prof_gemm_end()
+    assert n == 1 and 0.0 < ms < 50.0
+    tf, gb, ghz = hip.prof_peaks(mfma_iters=2000, copy_bytes=1 << 26, copy_reps=2)
+    assert 500.0 < tf < 2600.0 and 500.0 < gb < 8000.0 and 1.0 < ghz < 2.6     # the chip clocks to its power budget under the MFMA loop
