@@ -693,3 +693,18 @@ def test_get_word_inds_reference_fixture(golden_dir):
     assert multi >= 5                                     # words split into several pieces / repeated words are covered
     assert get_word_inds("a photo of a running dog", [0, 4], tok).tolist() == sorted(
         get_word_inds("a photo of a running dog", 0, tok).tolist() + get_word_inds("a photo of a running dog", 4, tok).tolist())
+
+
+def test_built_library_matches_the_sources_in_the_tree():
+    """The .so is git-ignored and travels prebuilt.  build() leaves uspace_amd/csrc/_build/BUILD_STAMP.json (sha256 of the library
+    and of every source it was built from): the library in the tree must be that library, built from the sources in the tree."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    path = os.path.join(ROOT, "uspace_amd", "csrc", "_build", "BUILD_STAMP.json")
+    if not os.path.exists(path):
+        pytest.skip("no build stamp: __graft_entry__.build() has not run in this checkout")
+    old, now = json.load(open(path)), ge.build_stamp()
+    assert old["library_sha256"] == now["library_sha256"], "libuspace_hip.so changed since build() stamped it"
+    assert old["sources"] == now["sources"], [k for k in now["sources"] if old["sources"].get(k) != now["sources"][k]]
+    assert "uspace_amd/csrc/gemm.hip" in now["sources"]
