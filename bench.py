@@ -404,9 +404,9 @@ def main():
                 r = max(fc1, key=lambda q: q["launches"])
                 import ctypes
                 out = (ctypes.c_int * 8)()
-                _hip.check(_hip.lib().uspace_gemm_plan(r["M"], r["N"], out), "uspace_gemm_plan")
+                _hip.check(_hip.lib().uspace_gemm_plan_k(r["M"], r["N"], r["K"], 0, out), "uspace_gemm_plan_k")
                 tile = f"{out[2]},{out[3]}"
-                waves = {(256, 256): "2,4", (192, 256): "2,4", (256, 128): "4,2", (128, 128): "2,2"}[(out[2], out[3])]
+                waves = {(256, 256): "2,4", (192, 256): "2,4", (256, 128): "4,2", (128, 128): "2,2", (64, 64): "2,2"}[(out[2], out[3])]
                 traffic, tnote = fc1_traffic(args.model, B, (out[2], out[3]))
                 line["roofline"] = {"bound": "mfma", "kernel": f"gemm_kernel<{tile},{waves}," + ("LN_IN|" if fold else "") + "BIAS|GELU|OUT_BF16> (fc1)",
                                     "achieved": r["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",

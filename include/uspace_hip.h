@@ -125,6 +125,9 @@ USPACE_API int uspace_gemm_tile_choice(int M, int N, int* split_rows);
  * 16-row remainder strips (each owned by the workgroups of one tile row), workgroups per round of 256 CUs}.  For choice 3 the
  * fields after split_rows describe the 256x256 launch over rows [0, split_rows). */
 USPACE_API int uspace_gemm_plan(int M, int N, int* out);
+/* ... of a launch with this K (and role: producer of LayerNorm partial sums or not): few-tile launches with K < 2048 use 64x64
+ * tiles (out[0] = 5, out[2] = out[3] = 64) */
+USPACE_API int uspace_gemm_plan_k(int M, int N, int K, int producer, int* out);
 
 /* Sum of row-shifted GEMMs:  acc[m, n] = sum_t A[m + row_shift[t], 0:K1] . W[n, t*K1:(t+1)*K1]  (+ epilogue
  * as above).  With rows = pixels of a zero-bordered NHWC map [B, H+2, W+2, C] and the 9 shifts

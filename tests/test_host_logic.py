@@ -594,6 +594,13 @@ def test_gemm_plans_on_random_shapes():
             got = L.uspace_gemm_part_slots_k(M, N, Kq)
             assert got == (-(-N // 64) if t else -(-N // 128) if narrow else -(-N // 256)), (M, N, Kq)
         assert L.uspace_gemm_part_slots(M, N) == L.uspace_gemm_part_slots_k(M, N, 64)
+        out_k = (ctypes.c_int * 8)()
+        for prod in (0, 1):
+            assert L.uspace_gemm_plan_k(M, N, K, prod, out_k) == 0
+            want_tiny = choice == 2 and -(-M // 128) * -(-N // 128) <= 160 and K < 2048 and (not prod or -(-N // 64) <= 8)
+            assert (out_k[0] == 5) == want_tiny and ((out_k[2], out_k[3]) == (64, 64)) == want_tiny
+            if want_tiny:
+                assert out_k[5] == -(-N // 64) and out_k[4] * 64 <= M + 63
         ws = L.uspace_gemm_split_ws_bytes(M, N, K)
         if ws:
             S = ws // (M * N * 4)

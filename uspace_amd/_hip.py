@@ -71,6 +71,7 @@ SIGNATURES = {
     "uspace_uvit_get_ln_fold": (_I, []),
     "uspace_gemm_tile_choice": (_I, [_I, _I, ctypes.POINTER(_I)]),
     "uspace_gemm_plan": (_I, [_I, _I, ctypes.POINTER(_I)]),
+    "uspace_gemm_plan_k": (_I, [_I, _I, _I, _I, ctypes.POINTER(_I)]),
     "uspace_gemm_slabs_bf16": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, ctypes.POINTER(_I), _I, _P, _P, _I, _P, _I, _P, _I, _P]),
     "uspace_layernorm_f32_bf16": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     "uspace_attention_bf16": (_I, [_P, _P, _P, _I, _I, _I, _P]),

@@ -1092,6 +1092,20 @@ extern "C" int uspace_gemm_plan(int M, int N, int* out) {
     return USPACE_OK;
 }
 
+// ... for a launch with this K and role (producer of LayerNorm partial sums or not): adds the 64x64 form (out[0] = 5)
+extern "C" int uspace_gemm_plan_k(int M, int N, int K, int producer, int* out) {
+    if (K <= 0) return USPACE_ERR_ARG;
+    US_TRY(uspace_gemm_plan(M, N, out));
+    TileChoice tc = (TileChoice)out[0];
+    if (producer) tc = producer_tile(tc, N);
+    if (refine_small(tc, M, N, K, producer != 0) == TILE_TINY) {
+        const int tn = us_cdiv(N, 64);
+        const Plan p = plan_rows(M, 64, tn, 1024);
+        out[0] = (int)TILE_TINY; out[1] = 0; out[2] = 64; out[3] = 64; out[4] = p.tiles_m; out[5] = tn; out[6] = p.n_strip; out[7] = 1024;
+    }
+    return USPACE_OK;
+}
+
 extern "C" int uspace_gemm_bf16_ext(const uint16_t* A, int lda, const uint16_t* A2, int lda2, int K1,
                                     const uint16_t* W, int ldw, int M, int N, int K, int epi_flags,
                                     const float* bias, const float* resid_in, int ld_resid,
