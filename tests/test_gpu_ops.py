@@ -511,14 +511,18 @@ def test_layernorm_folded_through_gemms(hip, M, D, Kp, N2):
     (4 * 257, 512, 1024, "producer_2slab"),  # skip_linear: two K slabs, producer
     (1030, 260, 192, "bias_resid_f32_bf16"),  # ragged rows and columns
     (70, 64, 64, "f32"),                    # one tile row and a 6-row strip
+    (4 * 257, 512, 2048, "producer"),       # fc2 of the in-blocks: 32 K tiles through the four-stage ring, fused producer epilogue
+    (4 * 257, 512, 2048, "bias_resid_f32_bf16"),   # fc2 of the mid / out blocks
+    (1030, 256, 1024, "bias_gelu_bf16"),    # ring form, ragged rows (strip) and 16 K tiles
 ])
 def test_gemm_64x64_tile_form(hip, M, N, K, kind):
-    """Launches whose 128x128 tiling would fill 160 workgroups or fewer and whose K is below 2048 run as 64x64 tiles (round 3,
-    `refine_small` in gemm.hip): every epilogue family at the U-ViT-S batch-4 shapes against the oracle (libs/timm.py:106-112,
+    """Launches whose 128x128 tiling would fill 160 workgroups or fewer run as 64x64 tiles (round 3, `refine_small` in gemm.hip;
+    K loops of 16 tiles or more -- and shorter ones of up to 448 tiles -- in the four-stage ring form): every epilogue family at
+    the U-ViT-S batch-4 shapes against the oracle (libs/timm.py:106-112,
     libs/uvit.py:135-161), with the partial-sum slot count (64-wide) as the witness that this form is the one that ran."""
     import ctypes
     lib = hip.lib()
-    assert -(-M // 128) * -(-N // 128) <= 160 and K < 2048
+    assert -(-M // 128) * -(-N // 128) <= 160
     rng = np.random.default_rng(M * 7 + N + K)
     A = bf16_round(_rand(rng, M, K))
     W = bf16_round(_rand(rng, N, K) * 0.1)
@@ -527,7 +531,7 @@ def test_gemm_64x64_tile_form(hip, M, N, K, kind):
     dA, dW, db = to_dev(A, torch.bfloat16), to_dev(W, torch.bfloat16), to_dev(b)
     if kind.startswith("producer"):
         slots = lib.uspace_gemm_part_slots_k(M, N, K)
-        assert slots == -(-N // 64) and lib.uspace_gemm_part_slots_k(M, N, 4096) == -(-N // 128)
+        assert slots == -(-N // 64) and lib.uspace_gemm_part_slots_k(M, N, 4096) == -(-N // 64)     # every K: the long-K ring form
         c = R.mean(axis=1).astype(np.float32)
         ref = C.linear(A, W, b) + R
         x = to_dev(R).clone()

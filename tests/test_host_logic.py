@@ -587,17 +587,16 @@ def test_gemm_plans_on_random_shapes():
         # producers of LayerNorm partial sums: 128-wide slots for the 128x128 form, and for the 256x128 form only while that makes at
         # most 8 of them (the consumers read up to 8): wider N falls back to 256-wide tiles
         narrow = choice == 2 or (choice == 4 and -(-N // 128) <= 8)
-        # ... and 64-wide slots where the 128x128 tiling would fill 160 workgroups or fewer, the K loop is short (< 2048) and
-        # that makes at most 8 slots (uspace_gemm_part_slots = the count for short K loops = the largest over K)
+        # ... and 64-wide slots where the 128x128 tiling would fill 160 workgroups or fewer and that makes at most 8 slots
         tiny = choice == 2 and -(-M // 128) * -(-N // 128) <= 160 and -(-N // 64) <= 8
-        for Kq, t in ((K, tiny and K < 2048), (64, tiny)):
+        for Kq, t in ((K, tiny), (64, tiny)):
             got = L.uspace_gemm_part_slots_k(M, N, Kq)
             assert got == (-(-N // 64) if t else -(-N // 128) if narrow else -(-N // 256)), (M, N, Kq)
         assert L.uspace_gemm_part_slots(M, N) == L.uspace_gemm_part_slots_k(M, N, 64)
         out_k = (ctypes.c_int * 8)()
         for prod in (0, 1):
             assert L.uspace_gemm_plan_k(M, N, K, prod, out_k) == 0
-            want_tiny = choice == 2 and -(-M // 128) * -(-N // 128) <= 160 and K < 2048 and (not prod or -(-N // 64) <= 8)
+            want_tiny = choice == 2 and -(-M // 128) * -(-N // 128) <= 160 and (not prod or -(-N // 64) <= 8)
             assert (out_k[0] == 5) == want_tiny and ((out_k[2], out_k[3]) == (64, 64)) == want_tiny
             if want_tiny:
                 assert out_k[5] == -(-N // 64) and out_k[4] * 64 <= M + 63

@@ -129,7 +129,7 @@ __device__ __forceinline__ void wait_vm() {
 template <int BM, int BN, int WM, int WN, int FLAGS, bool XTRA, int NST = 2>
 // (second launch bound = waves per SIMD: the 4-wave 128x128 form shares a CU with a second workgroup, so its waves must
 // fit 256 registers; one instantiation had grown to 264)
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 2) ? 2 : 1) void gemm_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 64)) ? 2 : 1) void gemm_kernel(const GemmArgs g) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr int TM = BM / WM / 16;            // 16-row activation sub-tiles per wave
     constexpr int TN = BN / WN / 16;            // 16-col weight sub-tiles per wave
@@ -144,7 +144,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 2) ? 2 : 1) v
     constexpr int STAGE_BYTES = TILE_A_BYTES + TILE_W_BYTES + TILE_X_BYTES;
     static_assert(BM % ROWS_PER_ISSUE == 0 && BN % ROWS_PER_ISSUE == 0, "tile/threads mismatch");
     static_assert(TM % 2 == 0 && TN % WM == 0 && (WM == 2 || WM == 4), "wave tile shape");
-    static_assert(NST == 2 || (!XTRA && FLAGS == USPACE_EPI_OUT_F32), "the ring form: plain tiles, raw fp32 partial sums of a K range");
+    static_assert(NST == 2 || (!XTRA && FLAGS == USPACE_EPI_OUT_F32) || (BM == 64 && BN == 64),
+                  "the ring form: raw fp32 partial sums of a K range (K-split), or the 64 x 64 tiles with any epilogue");
     constexpr int IPT = ISSUES_A + ISSUES_W;    // LDS-DMA instructions per wave and K tile
     static_assert((NST - 1) * IPT < 64, "vmcnt is a 6-bit counter");
 
@@ -399,13 +400,23 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 2) ? 2 : 1) v
     if constexpr (NST > 2) {
         // ring of NST stages, all filled up front (the host guarantees nk >= NST); the first tile is waited for by count
         if constexpr (ROWV) fetch_rowv();
+        if constexpr (EARLY_EPI) load_epi_consts();
+        // two stages before the first wait, the others right behind the first barrier: with all NST requested up front the first
+        // tile queues behind them in the texture path (fc1 of U-ViT-S at 4 x 257 rows: 11.4 us against 9.8)
 #pragma unroll
-        for (int t = 0; t < NST; ++t) {
+        for (int t = 0; t < 2; ++t) {
             stage_a(t, t);
             stage_w(t, t);
         }
-        wait_vm<(NST - 1) * IPT>();
+        // (strip owners' first two waves have one more instruction per stage in flight: their count is a lower bound, they wait for
+        // an instruction of the second stage as well)
+        wait_vm<IPT>();
         __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int t = 2; t < NST; ++t) {
+            stage_a(t, t);
+            stage_w(t, t);
+        }
     } else {
         stage_a(0, 0);
         stage_w(0, 0);
@@ -487,6 +498,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 2) ? 2 : 1) v
     {                                                                                              \
         const char* cur = smem + (buf) * STAGE_BYTES;                                              \
         MMA(af0, wf0, 0, 0, 1)                                                                     \
+        MMA_X(xf0, wf0)                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         LOAD_A(af1, cur, 1, c_k0)                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                         \
@@ -496,10 +508,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 2) ? 2 : 1) v
         __builtin_amdgcn_sched_barrier(0);                                                         \
         LOAD_A(af0, cur, 0, c_k1)                                                                  \
         LOAD_W(wf1, cur, c_k1)                                                                     \
+        if constexpr (XTRA) { LOAD_X(xf1, cur, c_k1) }                                             \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         MMA(af1, wf0, 1, 1, HM)                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         MMA(af0, wf1, 0, 0, 1)                                                                     \
+        MMA_X(xf1, wf1)                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         LOAD_A(af1, cur, 1, c_k1)                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                         \
@@ -517,6 +531,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NST == 2) ? 2 : 1) v
             const char* nxt = smem + (nbuf) * STAGE_BYTES;                                         \
             LOAD_A(af0, nxt, 0, c_k0)                                                              \
             LOAD_W(wf0, nxt, c_k0)                                                                 \
+            if constexpr (XTRA) { LOAD_X(xf0, nxt, c_k0) }                                         \
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         MMA(af1, wf1, 1, HM / 2, HM)                                                               \
@@ -785,9 +800,13 @@ inline Plan plan_rows(int M, int BM, int tiles_n, int wg_per_round) {
     return best;
 }
 
-template <int BM, int BN, int WM, int WN, int FLAGS>
+template <int BM, int BN, int WM, int WN, int FLAGS, int NST = 2>
 int launch(const GemmArgs& a, hipStream_t s, int wg_per_round) {
     GemmArgs g = a;
+    if constexpr (NST > 2) {       // ring form over the whole K range: one K range per tile, outputs where the caller wants them
+        g.nk_split = g.K / BK;
+        g.split_stride = 0;
+    }
     g.tiles_n = us_cdiv(g.N, BN);
     const Plan p = plan_rows(g.M, BM, g.tiles_n, wg_per_round);
     g.tiles_m = p.tiles_m;
@@ -795,8 +814,8 @@ int launch(const GemmArgs& a, hipStream_t s, int wg_per_round) {
     g.n_strip = p.n_strip;
     const int rec = us_rec_begin(US_REC_GEMM, FLAGS, g.M, g.N, g.K, s);
     const dim3 grid(g.tiles_m * g.tiles_n), block(64 * WM * WN);
-    if (p.n_strip > 0) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, FLAGS, true>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, FLAGS, false>), grid, block, 0, s, g);
+    if (p.n_strip > 0) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, FLAGS, true, NST>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, FLAGS, false, NST>), grid, block, 0, s, g);
     us_rec_end(rec, s);
     US_CHECK_LAUNCH();
     return USPACE_OK;
@@ -967,13 +986,14 @@ TileChoice choose_tile(int M, int N, int* split_rows) {
     return best == cost_mid ? TILE_MID : TILE_SMALL;
 }
 
-// Fifth form, 64x64 tiles (4 waves, 2 x 2, 36 KiB of LDS): launches whose 128x128 tiling would leave a third or more of the
-// CUs without a workgroup, with a K loop short enough that latency -- not staging traffic -- is the cost (K < 2048; longer
-// K loops keep the K-split form of the 128x128 tiles).  Four times the workgroups, a quarter of the LDS-DMA issue per wave
-// and K tile: U-ViT-S at 4 x 257 rows proj 12.4 -> 7.7 us, qkv 9.7 -> 8.0, fc1 10.8 -> 9.4, skip_linear 15.8 (split) -> 11.5
-// (rocprofv3 kernel trace, `profiles/r03_gemm_ablation.md` section 7).  Producers of LayerNorm partial sums take it only while N / 64 <= 8.
+// Fifth form, 64x64 tiles (4 waves, 2 x 2, 18 KiB of LDS per stage): launches whose 128x128 tiling would leave a third or more of
+// the CUs without a workgroup -- latency, not staging traffic, is their cost.  Four times the workgroups, a quarter of the LDS-DMA
+// issue per wave and K tile; K loops of 16 tiles or more (and shorter ones of few tiles) run the four-stage ring, which takes a K
+// tile from 0.44 to 0.18 us and replaces the K-split + finish pair for long K.  U-ViT-S at 4 x 257 rows (rocprofv3 kernel traces,
+// `profiles/r03_gemm_ablation.md` sections 7 and 11): proj 12.4 -> 7.1 us, qkv 9.7 -> 7.0, fc1 10.8 -> 9.8, skip_linear 15.8 -> 8.8,
+// fc2 15.8 -> 12.4.  Producers of LayerNorm partial sums take it only while N / 64 <= 8.
 inline TileChoice refine_small(TileChoice tc, int M, int N, int K, bool producer) {
-    if (tc != TILE_SMALL || K >= 2048) return tc;
+    if (tc != TILE_SMALL) return tc;
     if ((long)us_cdiv(M, 128) * us_cdiv(N, 128) > 160) return tc;
     if (producer && us_cdiv(N, 64) > 8) return tc;
     return TILE_TINY;
@@ -1017,7 +1037,13 @@ int dispatch_tile(const GemmArgs& a, hipStream_t s) {
             if (rc != USPACE_OK) return rc;
             return launch<128, 128, 2, 2, FLAGS>(row_slice(a, m1, a.M), s, 512);
         }
-        case TILE_TINY: return launch<64, 64, 2, 2, FLAGS>(a, s, 1024);
+        case TILE_TINY:
+            // a 64 x 64 workgroup is latency-bound with one K tile of prefetch (0.44 us per K tile); with four stages filled up
+            // front and refilled behind every barrier it runs at 0.18 (`profiles/r03_gemm_ablation.md` section 11)
+            // (not for short K loops that already put two workgroups on every CU: fc1 of U-ViT-S, 512 tiles x 8 K tiles, 9.8 -> 11.2 us)
+            if (a.K / BK >= 16 || (a.K / BK >= RING_NST && (long)us_cdiv(a.M, 64) * us_cdiv(a.N, 64) <= 448))
+                return launch<64, 64, 2, 2, FLAGS, RING_NST>(a, s, 1024);
+            return launch<64, 64, 2, 2, FLAGS>(a, s, 1024);
         default: return launch<128, 128, 2, 2, FLAGS>(a, s, 512);
     }
 }
