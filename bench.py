@@ -156,20 +156,27 @@ def roofline_rows(recs, D):
     return rows
 
 
+GEMM_SOURCES = ("gemm.hip", "common.h")
+
+
 def fc1_traffic(model, B, tile):
     """HBM bytes per fc1 launch from the committed PMC pass (profiles/fc1_traffic.json) -- only when that pass was taken on the
-    gemm.hip that is being benchmarked (sha256 of the source) and on the same workload and tile form; otherwise null."""
+    GEMM sources that are being benchmarked (sha256 over gemm.hip + common.h) and on the same workload and tile form; otherwise null."""
     import hashlib
     tp = os.path.join(ROOT, "profiles", "fc1_traffic.json")
     if not os.path.exists(tp):
         return None, "no committed PMC pass"
     t = json.load(open(tp))
-    sha = hashlib.sha256(open(os.path.join(ROOT, "uspace_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()
-    if t.get("gemm_hip_sha256") != sha:
-        return None, f"profiles/fc1_traffic.json was measured on another gemm.hip ({str(t.get('gemm_hip_sha256'))[:12]} != {sha[:12]}): dropped"
+    h = hashlib.sha256()
+    for f in GEMM_SOURCES:                   # everything the GEMM kernels are compiled from
+        h.update(open(os.path.join(ROOT, "uspace_amd", "csrc", f), "rb").read())
+    sha = h.hexdigest()
+    if t.get("gemm_source_sha256") != sha:
+        return None, (f"profiles/fc1_traffic.json was measured on other GEMM sources ({str(t.get('gemm_source_sha256'))[:12]} != {sha[:12]}, "
+                      f"sha256 over {' + '.join(GEMM_SOURCES)}): dropped")
     if t.get("model") != model or t.get("batch") != B or list(t.get("tile", [])) != list(tile):
         return None, "profiles/fc1_traffic.json was measured on another workload / tile form: dropped"
-    return t.get("hbm_bytes_per_launch"), f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of {t.get('source')}, gemm.hip {sha[:12]}"
+    return t.get("hbm_bytes_per_launch"), f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of {t.get('source')}, {' + '.join(GEMM_SOURCES)} {sha[:12]}"
 
 
 # BASELINE.json configs[i-1] -> workload; "dopri5" = 50 fixed Dormand-Prince steps (301 NFE), "euler" = 50 Euler steps

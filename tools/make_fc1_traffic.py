@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/fc1_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh, stamped with the sha256 of
-the gemm.hip they were measured on, the workload and the tile form (bench.py drops the figure when any of them differs).
+the GEMM sources (gemm.hip + common.h) they were measured on, the workload and the tile form (bench.py drops the figure when any of them differs).
     python tools/make_fc1_traffic.py gpurun_out/r03_pmc_fetch.txt gpurun_out/r03_pmc_write.txt [tag]"""
 import hashlib
 import json
@@ -9,6 +9,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GEMM_SOURCES = ("gemm.hip", "common.h")       # as bench.py: everything the GEMM kernels are compiled from
 FC1 = re.compile(r"gemm_kernel<(\d+), (\d+), \d, \d, 83, (true|false)")      # LN_IN|BIAS|GELU|OUT_BF16 = 64+1+2+16
 
 
@@ -34,10 +35,13 @@ def main():
     f_kb, n, m = per_launch(fetch, "FETCH_SIZE")
     w_kb, _, _ = per_launch(write, "WRITE_SIZE")
     M, N, K = 64 * 257, 4096, 1024
-    sha = hashlib.sha256(open(os.path.join(ROOT, "uspace_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()
+    h = hashlib.sha256()
+    for f in GEMM_SOURCES:
+        h.update(open(os.path.join(ROOT, "uspace_amd", "csrc", f), "rb").read())
+    sha = h.hexdigest()
     out = {
         "kernel": f"gemm_kernel<{m.group(1)},{m.group(2)},LN_IN|BIAS|GELU|OUT_BF16> (fc1, M={M} N={N} K={K})",
-        "model": "L_u", "batch": 64, "tile": [int(m.group(1)), int(m.group(2))], "gemm_hip_sha256": sha,
+        "model": "L_u", "batch": 64, "tile": [int(m.group(1)), int(m.group(2))], "gemm_source_sha256": sha, "gemm_sources": list(GEMM_SOURCES),
         "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_round.sh {tag}) over "
                   f"tools/one_forward.py ({n} launches)",
         "fetch_size_kb_per_launch": f_kb, "write_size_kb_per_launch": w_kb,

@@ -40,34 +40,37 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// erf-GELU (nn.GELU default, reference libs/timm.py:97).  erf by Abramowitz-Stegun 7.1.26
-// (|abs error| <= 1.5e-7, far below the bf16 rounding of the stored result): one v_rcp, one v_exp and
-// a handful of FMAs instead of libm's branchy erff (which cost ~16 us per 256x256 tile round in the fc1 epilogue).
-// With x = |v| / sqrt(2), t = 1 / (1 + p x), P(t) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))), w = P(t) exp(-x^2) / 2
-// (0 < w <= 1/2):
-//   gelu(v) = v/2 (1 + sign(v) erf(x)) = max(v, 0) - |v| w = max(v - v w, v w)
-// (v >= 0: v - v w >= v w because w <= 1/2; v < 0: v w > v - v w for the same reason) -- no sign handling at all, and every
-// operation except the |v| inside t works on packed pairs.  The 1/2 is folded into the coefficients, 1/sqrt(2) into p and
-// the exponent.
-#define US_GELU_P 0.23164189f            /* 0.3275911 / sqrt(2) */
-#define US_GELU_A1 0.127414796f
-#define US_GELU_A2 (-0.142248368f)
-#define US_GELU_A3 0.7107068705f
-#define US_GELU_A4 (-0.7265760135f)
-#define US_GELU_A5 0.5307027145f
-#define US_GELU_E (-0.72134752044f)      /* -log2(e) / 2 */
+// erf-GELU (nn.GELU default, reference libs/timm.py:97):  gelu(v) = v Phi(v) = max(v, 0) - |v| w(|v|),  w(x) = Phi(-x) = erfc(x / sqrt 2) / 2.
+// log2 w(x) is smooth and nearly quadratic, so  w(x) = exp2(P(x))  with a degree-8 polynomial (weighted minimax fit on [0, 8] for the
+// absolute error of |v| w, evaluated in fp32 Horner form; beyond 8, |v| w < 1e-14 and x is clamped): |gelu - exact| <= 4.4e-7 |v|,
+// the fp32 rounding of v itself, far below the bf16 rounding of the stored result (oracle: erf() of libm, oracle/ops.c).
+// One v_exp_f32 and ten plain VALU operations per value; no reciprocal, no sign handling (the |.| and -|.| are source modifiers).
+// Round 1-2 used Abramowitz-Stegun 7.1.26 (v_rcp + v_exp + 12 operations, same accuracy): the fc1 epilogue is VALU-bound
+// (`profiles/r03_gemm_ablation.md` sections 2 and 15), libm's branchy erff cost ~16 us per 256x256 tile round before that.
+#define US_GELU_X 8.0f
+#define US_GELU_C0 (-9.999988739e-01f)
+#define US_GELU_C1 (-1.151123263e+00f)
+#define US_GELU_C2 (-4.591154377e-01f)
+#define US_GELU_C3 (-5.271419817e-02f)
+#define US_GELU_C4 7.333383560e-03f
+#define US_GELU_C5 (-3.233417964e-04f)
+#define US_GELU_C6 (-1.144627951e-04f)
+#define US_GELU_C7 2.508332872e-05f
+#define US_GELU_C8 (-1.690403274e-06f)
 __device__ __forceinline__ float gelu_erf(float v) {
-    const float t = __builtin_amdgcn_rcpf(fmaf(US_GELU_P, fabsf(v), 1.0f));
-    const float e = __builtin_amdgcn_exp2f(v * v * US_GELU_E);
-    float q = fmaf(US_GELU_A5, t, US_GELU_A4);
-    q = fmaf(q, t, US_GELU_A3);
-    q = fmaf(q, t, US_GELU_A2);
-    q = fmaf(q, t, US_GELU_A1);
-    const float m = v * (q * t * e);
-    return fmaxf(v - m, m);
+    const float x = fminf(fabsf(v), US_GELU_X);
+    float q = fmaf(US_GELU_C8, x, US_GELU_C7);
+    q = fmaf(q, x, US_GELU_C6);
+    q = fmaf(q, x, US_GELU_C5);
+    q = fmaf(q, x, US_GELU_C4);
+    q = fmaf(q, x, US_GELU_C3);
+    q = fmaf(q, x, US_GELU_C2);
+    q = fmaf(q, x, US_GELU_C1);
+    q = fmaf(q, x, US_GELU_C0);
+    return fmaf(-fabsf(v), __builtin_amdgcn_exp2f(q), fmaxf(v, 0.f));
 }
 // The same over NV x 4 values stage by stage: every stage is NV x 4 independent instructions, so the dependent chain of
-// one value (about a dozen operations of 4-8 cycles latency each) is covered by the others.  The one-value-at-a-time
+// one value (a dozen operations of 4-8 cycles latency each) is covered by the others.  The one-value-at-a-time
 // form made the fc1 epilogue latency-bound (ISA: one pair of values after the other).
 // Stage boundary: the empty asm statements pin every value of the finished stage at this point of the IR (the
 // optimiser otherwise sinks a value's whole chain next to its use), the scheduling barrier keeps the machine scheduler
@@ -77,64 +80,40 @@ __device__ __forceinline__ float gelu_erf(float v) {
     __builtin_amdgcn_sched_barrier(0);
 template <int NV>
 __device__ __forceinline__ void gelu_erf_batch(f32x4 (&v)[NV]) {
-    f32x4 t[NV], e[NV], q[NV];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        // 1 + p |v|: one v_fma_f32 per value with the |.| source modifier (packed fp32 instructions have no abs; left to the
-        // compiler this becomes a v_and_b32 per value plus a packed fma per pair)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) asm("v_fma_f32 %0, |%1|, %2, 1.0" : "=v"(t[j][c]) : "v"(v[j][c]), "s"(US_GELU_P));
-        e[j] = v[j] * v[j];            // whole-vector forms: packed multiplies
-        e[j] = e[j] * US_GELU_E;
-    }
-    US_STAGE_END(t)
-    US_STAGE_END(e)
+    f32x4 x[NV], q[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) t[j][c] = __builtin_amdgcn_rcpf(t[j][c]);
-    US_STAGE_END(t)
+        for (int c = 0; c < 4; ++c) asm("v_min_f32 %0, |%1|, %2" : "=v"(x[j][c]) : "v"(v[j][c]), "s"(US_GELU_X));
+    US_STAGE_END(x)
+#pragma unroll
+    for (int j = 0; j < NV; ++j) q[j] = x[j] * US_GELU_C8 + US_GELU_C7;
+    US_STAGE_END(q)
+#define US_GELU_STEP(CK)                                           \
+    _Pragma("unroll") for (int j = 0; j < NV; ++j) q[j] = q[j] * x[j] + (CK); \
+    US_STAGE_END(q)
+    US_GELU_STEP(US_GELU_C6)
+    US_GELU_STEP(US_GELU_C5)
+    US_GELU_STEP(US_GELU_C4)
+    US_GELU_STEP(US_GELU_C3)
+    US_GELU_STEP(US_GELU_C2)
+    US_GELU_STEP(US_GELU_C1)
+    US_GELU_STEP(US_GELU_C0)
+#undef US_GELU_STEP
 #pragma unroll
     for (int j = 0; j < NV; ++j)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) e[j][c] = __builtin_amdgcn_exp2f(e[j][c]);
-    US_STAGE_END(e)
-#pragma unroll
-    for (int j = 0; j < NV; ++j) q[j] = t[j] * US_GELU_A5 + US_GELU_A4;
+        for (int c = 0; c < 4; ++c) q[j][c] = __builtin_amdgcn_exp2f(q[j][c]);
     US_STAGE_END(q)
 #pragma unroll
-    for (int j = 0; j < NV; ++j) q[j] = q[j] * t[j] + US_GELU_A3;
-    US_STAGE_END(q)
+    for (int j = 0; j < NV; ++j)
 #pragma unroll
-    for (int j = 0; j < NV; ++j) q[j] = q[j] * t[j] + US_GELU_A2;
-    US_STAGE_END(q)
+        for (int c = 0; c < 4; ++c) asm("v_max_f32 %0, %1, 0" : "=v"(x[j][c]) : "v"(v[j][c]));     // (fmaxf() adds a NaN-quieting v_max)
+    US_STAGE_END(x)
 #pragma unroll
-    for (int j = 0; j < NV; ++j) q[j] = q[j] * t[j] + US_GELU_A1;
-    US_STAGE_END(q)
+    for (int j = 0; j < NV; ++j)
 #pragma unroll
-    for (int j = 0; j < NV; ++j) t[j] = t[j] * e[j];
-    US_STAGE_END(t)
-#pragma unroll
-    for (int j = 0; j < NV; ++j) q[j] = q[j] * t[j];
-    US_STAGE_END(q)
-#pragma unroll
-    for (int j = 0; j < NV; ++j) q[j] = v[j] * q[j];       // m = v w
-    US_STAGE_END(q)
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        // (inline asm: fmaxf() costs a second v_max per value to quiet NaNs, and the subtraction is not packed by itself)
-        typedef __attribute__((ext_vector_type(2))) float f32x2_;
-#pragma unroll
-        for (int c = 0; c < 4; c += 2) {
-            f32x2_ d;
-            const f32x2_ a = {v[j][c], v[j][c + 1]}, b = {q[j][c], q[j][c + 1]};
-            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-            t[j][c] = d[0];
-            t[j][c + 1] = d[1];
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) asm("v_max_f32 %0, %1, %2" : "=v"(v[j][c]) : "v"(t[j][c]), "v"(q[j][c]));
-    }
+        for (int c = 0; c < 4; ++c) asm("v_fma_f32 %0, -|%1|, %2, %3" : "=v"(v[j][c]) : "v"(v[j][c]), "v"(q[j][c]), "v"(x[j][c]));
     US_STAGE_END(v)
 }
 #undef US_STAGE_END
