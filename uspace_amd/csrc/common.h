@@ -43,7 +43,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // erf-GELU (nn.GELU default, reference libs/timm.py:97):  gelu(v) = v Phi(v) = max(v, 0) - |v| w(|v|),  w(x) = Phi(-x) = erfc(x / sqrt 2) / 2.
 // log2 w(x) is smooth and nearly quadratic, so  w(x) = exp2(P(x))  with a degree-8 polynomial (weighted minimax fit on [0, 8] for the
 // absolute error of |v| w, evaluated in fp32 Horner form; beyond 8, |v| w < 1e-14 and x is clamped): |gelu - exact| <= 4.4e-7 |v|,
-// the fp32 rounding of v itself, far below the bf16 rounding of the stored result (oracle: erf() of libm, oracle/ops.c).
+// the fp32 rounding of v itself, far below the bf16 rounding of the stored result (the parity tests compare with libm's erf).
 // One v_exp_f32 and ten plain VALU operations per value; no reciprocal, no sign handling (the |.| and -|.| are source modifiers).
 // Round 1-2 used Abramowitz-Stegun 7.1.26 (v_rcp + v_exp + 12 operations, same accuracy): the fc1 epilogue is VALU-bound
 // (`profiles/r03_gemm_ablation.md` sections 2 and 15), libm's branchy erff cost ~16 us per 256x256 tile round before that.
