@@ -138,6 +138,13 @@ enum { US_REC_GEMM = 0, US_REC_ATTENTION = 1 };
 int us_rec_begin(int kind, int flags, int M, int N, int K, hipStream_t s);
 void us_rec_end(int idx, hipStream_t s);
 
+// Output head with its LayerNorm-folded decoder weights prepared once at pack time (rowops.hip; used by uvit.hip, not exported)
+size_t us_head_image_floats(int D);
+int us_head_pack(const float* norm_g, const float* norm_b, const float* dec_w, const float* dec_b, int PD, int D, float* image,
+                 hipStream_t s);
+int us_output_head_packed(const float* tok, int L, int extras, const float* image, const float* conv_w, const float* conv_b,
+                          float* scratch, float* out, int B, int C, int S, int p, int D, float eps, hipStream_t s);
+
 // Opt a kernel in to more than 64 KiB of dynamic LDS.  The attribute is per DEVICE: `done` (one per kernel, static at the
 // launch site) records the devices already served as a bit mask, so a process that drives several GPUs sets it on each
 // of them, and concurrent host threads at worst set it twice.  Devices >= 64 set it on every launch.

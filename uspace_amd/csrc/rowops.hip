@@ -386,7 +386,54 @@ __global__ __launch_bounds__(256) void head_pred_kernel(const float* __restrict_
 // token and step), so mean and centred second moment are per-lane sums plus two cross-lane steps, and the MFMA
 // result leaves lane (fr, fq) holding outputs 4*fq..4*fq+3 of token fr -- no other reduction.  gamma-folded weights sit
 // in LDS as [k/8][16 rows][8] bf16 (hi and lo): a fragment read is 1 KB contiguous per wave.
-template <int UNR>
+// The weight image of the fast path: wh / wl = [D/8][16 rows] x 16 B (bf16 hi and lo parts of gamma_k W_ok, rows >= PD zero),
+// cst[o] = b_o + sum_k beta_k W_ok.  Built by one 256-thread block, either into LDS (uspace_output_head: every block for itself)
+// or once at pack time into global memory (us_head_pack; the kernel then copies 64 D + 64 bytes instead of rebuilding them).
+__device__ __forceinline__ void head_weight_image(const float* __restrict__ ng, const float* __restrict__ nb,
+                                                  const float* __restrict__ dw, const float* __restrict__ db, int PD, int D,
+                                                  uint4* wh, uint4* wl, float* red, float* cst) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float part = 0.f;                                        // thread (row = tid & 15) accumulates beta . W_row over its chunks
+    const int row = tid & 15;
+    for (int c = tid >> 4; c < (D >> 3); c += 16) {
+        union { uint32_t w[4]; uint4 v; } hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float h2[2], l2[2];
+#pragma unroll
+            for (int z = 0; z < 2; ++z) {
+                const int k = c * 8 + 2 * e + z;
+                const float wv = row < PD ? dw[(size_t)row * D + k] : 0.f;
+                part += nb[k] * wv;
+                const float gw = ng[k] * wv;
+                h2[z] = bf2f(f2bf(gw));
+                l2[z] = gw - h2[z];
+            }
+            hi.w[e] = pack_bf2(h2[0], h2[1]);
+            lo.w[e] = pack_bf2(l2[0], l2[1]);
+        }
+        wh[c * 16 + row] = hi.v;
+        wl[c * 16 + row] = lo.v;
+    }
+    // reduce `part` over the 16 threads-per-row groups: lanes with equal (lane & 15) inside a wave, then the waves
+    part += __shfl_xor(part, 16, 64);
+    part += __shfl_xor(part, 32, 64);
+    if (lane < 16) red[wave * 16 + lane] = part;
+    __syncthreads();
+    if (tid < 16) cst[tid] = (tid < PD ? db[tid] : 0.f) + ((red[tid] + red[16 + tid]) + (red[32 + tid] + red[48 + tid]));
+    __syncthreads();
+}
+
+// image layout in global memory: [wh: 2 D uint4][wl: 2 D uint4][cst: 16 floats]
+__global__ __launch_bounds__(256) void head_pack_kernel(const float* __restrict__ ng, const float* __restrict__ nb,
+                                                        const float* __restrict__ dw, const float* __restrict__ db, int PD, int D,
+                                                        uint4* __restrict__ image) {
+    __shared__ float red[64];
+    head_weight_image(ng, nb, dw, db, PD, D, image, image + 2 * D, red, (float*)(image + 4 * D));
+}
+
+// PACKED: `dw` is the image head_pack_kernel wrote (ng / nb / db unused)
+template <int UNR, bool PACKED>
 __global__ __launch_bounds__(256) void head_pred_mfma_kernel(const float* __restrict__ tok, int L, int extras,
                                                              const float* __restrict__ ng, const float* __restrict__ nb,
                                                              const float* __restrict__ dw, const float* __restrict__ db,
@@ -396,39 +443,15 @@ __global__ __launch_bounds__(256) void head_pred_mfma_kernel(const float* __rest
     const int PD = p * p * C;                                    // <= 16 (rows >= PD are zero)
     uint4* wh = (uint4*)hsm;                                     // [D/8][16] x 16 B
     uint4* wl = wh + 2 * D;
-    float* red = (float*)(wl + 2 * D);                           // [4 waves][16]
-    float* cst = red + 64;
+    float* cst = (float*)(wl + 2 * D);                           // 16 floats, then [4 waves][16] reduction scratch
+    float* red = cst + 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    {
-        float part = 0.f;                                        // thread (row = tid & 15) accumulates beta . W_row over its chunks
-        const int row = tid & 15;
-        for (int c = tid >> 4; c < (D >> 3); c += 16) {
-            union { uint32_t w[4]; uint4 v; } hi, lo;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float h2[2], l2[2];
-#pragma unroll
-                for (int z = 0; z < 2; ++z) {
-                    const int k = c * 8 + 2 * e + z;
-                    const float wv = row < PD ? dw[(size_t)row * D + k] : 0.f;
-                    part += nb[k] * wv;
-                    const float gw = ng[k] * wv;
-                    h2[z] = bf2f(f2bf(gw));
-                    l2[z] = gw - h2[z];
-                }
-                hi.w[e] = pack_bf2(h2[0], h2[1]);
-                lo.w[e] = pack_bf2(l2[0], l2[1]);
-            }
-            wh[c * 16 + row] = hi.v;
-            wl[c * 16 + row] = lo.v;
-        }
-        // reduce `part` over the 16 threads-per-row groups: lanes with equal (lane & 15) inside a wave, then the waves
-        part += __shfl_xor(part, 16, 64);
-        part += __shfl_xor(part, 32, 64);
-        if (lane < 16) red[wave * 16 + lane] = part;
+    if constexpr (PACKED) {
+        const uint4* src = (const uint4*)dw;
+        for (int i = tid; i < 4 * D + 4; i += 256) wh[i] = src[i];      // wh, wl and cst are contiguous in both places
         __syncthreads();
-        if (tid < 16) cst[tid] = (tid < PD ? db[tid] : 0.f) + ((red[tid] + red[16 + tid]) + (red[32 + tid] + red[48 + tid]));
-        __syncthreads();
+    } else {
+        head_weight_image(ng, nb, dw, db, PD, D, wh, wl, red, cst);
     }
     const int g = S / p;
     const int npatch = g * g;
@@ -773,14 +796,45 @@ extern "C" int uspace_output_head(const float* tok, int L, int extras, const flo
     if ((D & 31) == 0 && D <= 2048) {
         const size_t lds = (size_t)64 * D + (64 + 16) * 4;
         static std::atomic<uint64_t> lds_ok{0};
-        US_TRY(us_opt_in_lds((const void*)head_pred_mfma_kernel<8>, 140 * 1024, lds_ok));
-        hipLaunchKernelGGL(head_pred_mfma_kernel<8>, dim3(us_cdiv(B * g * g, 64)), dim3(256), lds, s, tok, L, extras, norm_g,
+        US_TRY(us_opt_in_lds((const void*)head_pred_mfma_kernel<8, false>, 140 * 1024, lds_ok));
+        hipLaunchKernelGGL((head_pred_mfma_kernel<8, false>), dim3(us_cdiv(B * g * g, 64)), dim3(256), lds, s, tok, L, extras, norm_g,
                            norm_b, dec_w, dec_b, scratch, B, C, S, p, D, eps);
     } else if (D <= 256) hipLaunchKernelGGL(head_pred_kernel<1>, hgrid, hblock, 0, s, tok, L, extras, norm_g, norm_b, dec_w, dec_b, scratch, B, C, S, p, D, eps);
     else if (D <= 512) hipLaunchKernelGGL(head_pred_kernel<2>, hgrid, hblock, 0, s, tok, L, extras, norm_g, norm_b, dec_w, dec_b, scratch, B, C, S, p, D, eps);
     else if (D <= 1024) hipLaunchKernelGGL(head_pred_kernel<4>, hgrid, hblock, 0, s, tok, L, extras, norm_g, norm_b, dec_w, dec_b, scratch, B, C, S, p, D, eps);
     else if (D <= 2048) hipLaunchKernelGGL(head_pred_kernel<8>, hgrid, hblock, 0, s, tok, L, extras, norm_g, norm_b, dec_w, dec_b, scratch, B, C, S, p, D, eps);
     else return USPACE_ERR_ARG;
+    US_CHECK_LAUNCH();
+    const long total = (long)B * C * S * S;
+    hipLaunchKernelGGL(conv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, scratch, conv_w, conv_b,
+                       out, B, C, S);
+    US_CHECK_LAUNCH();
+    return USPACE_OK;
+}
+
+// Pack-time half of the output head's fast path (uvit.hip keeps the image in the weight blob): see head_weight_image.
+size_t us_head_image_floats(int D) { return (size_t)16 * D + 16; }
+
+int us_head_pack(const float* norm_g, const float* norm_b, const float* dec_w, const float* dec_b, int PD, int D, float* image,
+                 hipStream_t s) {
+    if (!norm_g || !norm_b || !dec_w || !dec_b || !image || PD <= 0 || PD > 16 || (D & 31) || D > 2048) return USPACE_ERR_ARG;
+    hipLaunchKernelGGL(head_pack_kernel, dim3(1), dim3(256), 0, s, norm_g, norm_b, dec_w, dec_b, PD, D, (uint4*)image);
+    US_CHECK_LAUNCH();
+    return USPACE_OK;
+}
+
+// uspace_output_head with the weight image of us_head_pack instead of norm / decoder_pred parameters
+int us_output_head_packed(const float* tok, int L, int extras, const float* image, const float* conv_w, const float* conv_b,
+                          float* scratch, float* out, int B, int C, int S, int p, int D, float eps, hipStream_t s) {
+    if (!tok || !image || !conv_w || !conv_b || !scratch || !out) return USPACE_ERR_ARG;
+    if (B <= 0 || (D & 31) || D > 2048 || S % p || p * p * C > 16) return USPACE_ERR_ARG;
+    const int g = S / p;
+    if (extras + g * g != L) return USPACE_ERR_ARG;
+    const size_t lds = (size_t)64 * D + (64 + 16) * 4;
+    static std::atomic<uint64_t> lds_ok{0};
+    US_TRY(us_opt_in_lds((const void*)head_pred_mfma_kernel<8, true>, 140 * 1024, lds_ok));
+    hipLaunchKernelGGL((head_pred_mfma_kernel<8, true>), dim3(us_cdiv(B * g * g, 64)), dim3(256), lds, s, tok, L, extras, nullptr,
+                       nullptr, image, nullptr, scratch, B, C, S, p, D, eps);
     US_CHECK_LAUNCH();
     const long total = (long)B * C * S * S;
     hipLaunchKernelGGL(conv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, scratch, conv_w, conv_b,

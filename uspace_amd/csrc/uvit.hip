@@ -48,6 +48,7 @@ struct Model {
     int pos, pw, pb, cw = -1, cb = -1;
     std::vector<BlockIdx> blk;
     int ng, nb, dw, db, convw, convb;
+    int head_img = -1;   // derived: the output head's weight image (rowops.hip head_weight_image), when the fast path applies
     int L, extras, npatch, nblocks;
     int n_params;   // entries of lay.p that are parameters; the rest are derived tensors
 };
@@ -116,6 +117,7 @@ Model build_model(const uspace_uvit_config& c) {
         b.fc1_fb = m.lay.add(Hd, F32);
         b.fc1_cs = m.lay.add(Hd, F32);
     }
+    if ((D & 31) == 0 && D <= 2048) m.head_img = m.lay.add((long)us_head_image_floats((int)D), F32);
     return m;
 }
 
@@ -200,6 +202,9 @@ extern "C" int uspace_uvit_pack_weights(const uspace_uvit_config* cfg, const flo
         US_TRY(uspace_fold_layernorm(params[b.fc1w], params[b.n2w], params[b.n2b], params[b.fc1b], (uint16_t*)at(b.fc1_f),
                                      (float*)at(b.fc1_fb), (float*)at(b.fc1_cs), Hd, D, stream));
     }
+    if (m.head_img >= 0)
+        US_TRY(us_head_pack(params[m.ng], params[m.nb], params[m.dw], params[m.db], cfg->patch_size * cfg->patch_size * cfg->in_chans, D,
+                            (float*)at(m.head_img), s));
     return USPACE_OK;
 }
 
@@ -378,8 +383,12 @@ extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* bl
         }
     }
     }
-    US_TRY(uspace_output_head(x, L, m.extras, PF(m.ng), PF(m.nb), PF(m.dw), PF(m.db), PF(m.convw), PF(m.convb),
-                              (float*)(ws + w.head), io->out, B, c.in_chans, c.img_size, c.patch_size, D, 1e-5f, stream));
+    if (m.head_img >= 0)     // decoder weights with the last LayerNorm folded in, prepared by uspace_uvit_pack_weights
+        US_TRY(us_output_head_packed(x, L, m.extras, PF(m.head_img), PF(m.convw), PF(m.convb), (float*)(ws + w.head), io->out, B,
+                                     c.in_chans, c.img_size, c.patch_size, D, 1e-5f, (hipStream_t)stream));
+    else
+        US_TRY(uspace_output_head(x, L, m.extras, PF(m.ng), PF(m.nb), PF(m.dw), PF(m.db), PF(m.convw), PF(m.convb),
+                                  (float*)(ws + w.head), io->out, B, c.in_chans, c.img_size, c.patch_size, D, 1e-5f, stream));
     return USPACE_OK;
 }
 
