@@ -447,9 +447,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
             asm volatile("ds_write_b64 %0, %1" ::"v"(rowv_lds + (uint32_t)tid * 8u), "v"(v) : "memory");
         }
     }
-    LOAD_A(af0, smem, 0, c_k0)
-    LOAD_W(wf0, smem, c_k0)
-    if constexpr (XTRA) { LOAD_X(xf0, smem, c_k0) }
+    // 64 x 64 tiles in the ring form keep the fragments of a whole K tile in registers, fetched one tile ahead (see KTILE_T below)
+#ifndef USPACE_RING_PREFETCH_ALL
+#define USPACE_RING_PREFETCH_ALL 0
+#endif
+    constexpr bool TINYK = NST > 2 && ((BM == 64 && BN == 64) || USPACE_RING_PREFETCH_ALL);
+    if constexpr (!TINYK) {
+        LOAD_A(af0, smem, 0, c_k0)
+        LOAD_W(wf0, smem, c_k0)
+        if constexpr (XTRA) { LOAD_X(xf0, smem, c_k0) }
+    }
 
 #define KTILE(kt, MORE, MORE2)                                                                     \
     {                                                                                              \
@@ -537,18 +544,99 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         MMA(af1, wf1, 1, HM / 2, HM)                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                         \
     }
-    if constexpr (NST > 2) {
+    if constexpr (TINYK) {
+        // A lone 64 x 64 workgroup (one wave per SIMD) has 8 MFMAs per wave and K tile: interleaved with their fragment reads as above,
+        // every K tile exposes four LDS round trips (0.25 us per tile whatever the ring depth).  Here the 8 (+2) fragment reads of tile
+        // kt+1 are issued together right behind the barrier and the 8 MFMAs of tile kt run under them: two register sets, P / Q.
+        bf16x8 ta[2][2][TM], tw[2][2][TN], tx[2][2];
+#define T_LOAD(S, base)                                                                            \
+        _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                         \
+            const int ck_ = h_ ? c_k1 : c_k0;                                                      \
+            _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_)                                      \
+                ta[S][h_][i_] = *(const bf16x8*)((base) + a_lds + i_ * 16 * ROW_BYTES + ck_);      \
+            _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_)                                      \
+                tw[S][h_][j_] = *(const bf16x8*)((base) + w_lds + j_ * 16 * ROW_BYTES + ck_);      \
+            if constexpr (XTRA) {                                                                  \
+                if (has_x) tx[S][h_] = *(const bf16x8*)((base) + x_lds + ck_);                     \
+            }                                                                                      \
+        }
+#define T_MMA(S)                                                                                   \
+        _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                         \
+            _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_)                                      \
+                _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_)                                  \
+                    acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tw[S][h_][j_], ta[S][h_][i_], acc[i_][j_], 0, 0, 0); \
+            if (XTRA && has_x) {                                                                   \
+                _Pragma("unroll") for (int j_ = 0; j_ < XN; ++j_)                                  \
+                    xacc[j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pick_w<WM, XN>(tw[S][h_], wm, j_), tx[S][h_], xacc[j_], 0, 0, 0); \
+            }                                                                                      \
+        }
+        // barrier of tile kt: tile kt+1 has landed for everyone (counted wait) and everyone's reads of tile kt are complete (the
+        // lgkmcnt(0) of the same wait): the reads of tile kt+1 go out, tile kt's buffer is refilled with tile kt+NST, tile kt's MFMAs run
+#define KTILE_T(WAITN, REFILL, P, Q)                                                               \
+        {                                                                                          \
+            const int nb = buf + 1 == NST ? 0 : buf + 1;                                           \
+            /* the builtin, not inline asm: the backend's wait-count pass sees that set P has arrived (lgkmcnt 0) and does not */ \
+            /* wait for it again behind the reads of set Q; gfx9 encoding vm[3:0] | exp << 4 | lgkm << 8 | vm[5:4] << 14       */ \
+            __builtin_amdgcn_s_waitcnt(((WAITN) & 15) | (7 << 4) | (0 << 8) | ((((WAITN) >> 4) & 3) << 14)); \
+            __builtin_amdgcn_s_barrier();                                                          \
+            T_LOAD(Q, smem + nb * STAGE_BYTES)                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            /* the refill has the ring's slack: its address arithmetic runs beside the MFMAs, behind the fragment reads */ \
+            if (REFILL) {                                                                          \
+                stage_a(kt + NST, buf);                                                            \
+                stage_w(kt + NST, buf);                                                            \
+            }                                                                                      \
+            T_MMA(P)                                                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            buf = nb;                                                                              \
+            ++kt;                                                                                  \
+        }
+        int kt = 0, buf = 0;
+        T_LOAD(0, smem)
+        while (kt + NST + 1 < nk) {
+            KTILE_T((NST - 2) * IPT, true, 0, 1)
+            KTILE_T((NST - 2) * IPT, true, 1, 0)
+        }
+        if (kt + NST < nk) {                  // odd count of refilling tiles: one more, then the sets change names
+            KTILE_T((NST - 2) * IPT, true, 0, 1)
+#pragma unroll
+            for (int h_ = 0; h_ < 2; ++h_) {
+#pragma unroll
+                for (int i_ = 0; i_ < TM; ++i_) ta[0][h_][i_] = ta[1][h_][i_];
+#pragma unroll
+                for (int j_ = 0; j_ < TN; ++j_) tw[0][h_][j_] = tw[1][h_][j_];
+                tx[0][h_] = tx[1][h_];
+            }
+        }
+        // the last NST-1 barriers: nothing left to refill, the NST-2-J younger tiles stay in flight
+#define KTILE_TT(J)                                                                                \
+        if constexpr ((J) < NST - 1) { KTILE_T((NST - 2 - (J)) * IPT, false, (J) & 1, ((J) + 1) & 1) }
+        KTILE_TT(0) KTILE_TT(1) KTILE_TT(2) KTILE_TT(3) KTILE_TT(4) KTILE_TT(5) KTILE_TT(6)
+#undef KTILE_TT
+        static_assert(NST <= 8, "tail steps are written out up to NST = 8");
+        T_MMA((NST - 1) & 1)
+#undef KTILE_T
+#undef T_MMA
+#undef T_LOAD
+    } else if constexpr (NST > 2) {
         int kt = 0, buf = 0;
         for (; kt + NST < nk; ++kt) {
             const int nb = buf + 1 == NST ? 0 : buf + 1;
             KTILE_R(kt, buf, nb, true, true, (NST - 2) * IPT)
             buf = nb;
         }
-        for (; kt + 1 < nk; ++kt) {       // the last NST-1 barriers: nothing left to refill, wait for everything in flight
-            const int nb = buf + 1 == NST ? 0 : buf + 1;
-            KTILE_R(kt, buf, nb, true, false, 0)
-            buf = nb;
+        // the last NST-1 barriers (kt = nk-NST+J): nothing left to refill; tile kt+1 is waited for by count, the NST-2-J younger
+        // tiles stay in flight (waiting for all of them at the first of these barriers cost a deep ring its depth)
+#define KTILE_TAIL(J)                                                                              \
+        if constexpr ((J) < NST - 1) {                                                             \
+            const int nb = buf + 1 == NST ? 0 : buf + 1;                                           \
+            KTILE_R(kt, buf, nb, true, false, (NST - 2 - (J)) * IPT)                               \
+            buf = nb;                                                                              \
+            ++kt;                                                                                  \
         }
+        KTILE_TAIL(0) KTILE_TAIL(1) KTILE_TAIL(2) KTILE_TAIL(3) KTILE_TAIL(4) KTILE_TAIL(5) KTILE_TAIL(6)
+#undef KTILE_TAIL
+        static_assert(NST <= 8, "tail steps are written out up to NST = 8");
         KTILE_R(kt, buf, 0, false, false, 0)
     } else {
         // steady state is branch-free; the last two K tiles are peeled (no further prefetch / barrier)
@@ -1039,7 +1127,8 @@ int dispatch_tile(const GemmArgs& a, hipStream_t s) {
         }
         case TILE_TINY:
             // a 64 x 64 workgroup is latency-bound with one K tile of prefetch (0.44 us per K tile); with four stages filled up
-            // front and refilled behind every barrier it runs at 0.18 (`profiles/r03_gemm_ablation.md` section 11)
+            // front and refilled behind every barrier, and its fragments fetched a whole tile ahead (KTILE_T), it runs at 0.14-0.19
+            // (`profiles/r03_gemm_ablation.md` sections 11 and 17; eight stages are no faster than four)
             // (not for short K loops that already put two workgroups on every CU: fc1 of U-ViT-S, 512 tiles x 8 K tiles, 9.8 -> 11.2 us)
             if (a.K / BK >= 16 || (a.K / BK >= RING_NST && (long)us_cdiv(a.M, 64) * us_cdiv(a.N, 64) <= 448))
                 return launch<64, 64, 2, 2, FLAGS, RING_NST>(a, s, 1024);
