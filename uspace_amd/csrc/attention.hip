@@ -296,14 +296,17 @@ int launch_attn2(const bf16_t* qkv, const float* ks, bf16_t* out, int B, int L, 
     const size_t lds = (size_t)NT * 16 * KROW_BYTES + (size_t)NP * 32 * KROW_BYTES + (SCALED ? NT * 16 * 4 : 0);
     static std::atomic<uint64_t> lds_ok{0}, lds_ok_q4{0}, lds_ok_q2{0};
     const int rec = us_rec_begin(US_REC_ATTENTION, SCALED ? 1 : 0, B * H, L, 64, s);
-    if (B * H <= 64) {          // a quarter of the CUs or less: four workgroups per head (11.2 -> 6.4 us at B * H = 32)
-        US_TRY(us_opt_in_lds((const void*)attention_kernel<NT, LC, SCALED, NW, false, 4>, 160 * 1024, lds_ok_q4));
-        hipLaunchKernelGGL((attention_kernel<NT, LC, SCALED, NW, false, 4>), dim3(B * H * 4), dim3(64 * NW), lds, s, qkv, ks, out, L, H);
+    // a quarter of the CUs or less: as many workgroups per head as it takes to give every wave at most ONE query tile (17 tiles on 4-wave
+    // workgroups: 5, not 4 -- with 4 the first wave of a head runs two tiles back to back; 21 tiles on 8-wave workgroups: 3)
+    constexpr int QSMALL = (NT + NW - 1) / NW;
+    if (B * H <= 64) {
+        US_TRY(us_opt_in_lds((const void*)attention_kernel<NT, LC, SCALED, NW, false, QSMALL>, 160 * 1024, lds_ok_q4));
+        hipLaunchKernelGGL((attention_kernel<NT, LC, SCALED, NW, false, QSMALL>), dim3(B * H * QSMALL), dim3(64 * NW), lds, s, qkv, ks, out, L, H);
         us_rec_end(rec, s);
         US_CHECK_LAUNCH();
         return USPACE_OK;
     }
-    if (B * H <= 128) {         // half of the CUs: two (12.1 -> 8.9 us at B * H = 128; nothing above that)
+    if (B * H <= 128) {         // half of the CUs: two (12.1 -> 8.9 us at B * H = 128; three: no faster; nothing above that)
         US_TRY(us_opt_in_lds((const void*)attention_kernel<NT, LC, SCALED, NW, false, 2>, 160 * 1024, lds_ok_q2));
         hipLaunchKernelGGL((attention_kernel<NT, LC, SCALED, NW, false, 2>), dim3(B * H * 2), dim3(64 * NW), lds, s, qkv, ks, out, L, H);
         us_rec_end(rec, s);
