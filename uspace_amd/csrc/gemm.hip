@@ -1080,6 +1080,11 @@ TileChoice choose_tile(int M, int N, int* split_rows) {
 // tile from 0.44 to 0.18 us and replaces the K-split + finish pair for long K.  U-ViT-S at 4 x 257 rows (rocprofv3 kernel traces,
 // `profiles/r03_gemm_ablation.md` sections 7 and 11): proj 12.4 -> 7.1 us, qkv 9.7 -> 7.0, fc1 10.8 -> 9.8, skip_linear 15.8 -> 8.8,
 // fc2 15.8 -> 12.4.  Producers of LayerNorm partial sums take it only while N / 64 <= 8.
+constexpr int TINY_SLOTS = 1024, TINY_RING_SLOTS = 512;     // workgroups of the 64x64 form per round of the chip: two stages / ring
+// which K loop a 64x64 launch takes: the ring for K loops of 16 tiles or more and for shorter ones of few tiles
+inline bool tiny_ring(int M, int N, int K) {
+    return K / BK >= 16 || (K / BK >= RING_NST && (long)us_cdiv(M, 64) * us_cdiv(N, 64) <= 448);
+}
 inline TileChoice refine_small(TileChoice tc, int M, int N, int K, bool producer) {
     if (tc != TILE_SMALL) return tc;
     if ((long)us_cdiv(M, 128) * us_cdiv(N, 128) > 160) return tc;
@@ -1130,9 +1135,10 @@ int dispatch_tile(const GemmArgs& a, hipStream_t s) {
             // front and refilled behind every barrier, and its fragments fetched a whole tile ahead (KTILE_T), it runs at 0.14-0.19
             // (`profiles/r03_gemm_ablation.md` sections 11 and 17; eight stages are no faster than four)
             // (not for short K loops that already put two workgroups on every CU: fc1 of U-ViT-S, 512 tiles x 8 K tiles, 9.8 -> 11.2 us)
-            if (a.K / BK >= 16 || (a.K / BK >= RING_NST && (long)us_cdiv(a.M, 64) * us_cdiv(a.N, 64) <= 448))
-                return launch<64, 64, 2, 2, FLAGS, RING_NST>(a, s, 1024);
-            return launch<64, 64, 2, 2, FLAGS>(a, s, 1024);
+            // (the ring form holds 66-74 KiB of LDS: two workgroups per CU, 512 per round -- the row plan must know, or a remainder of
+            // a few rows becomes a second round instead of a strip: fc1 of U-ViT-L at 2 x 257 rows, 576 workgroups, 15.9 -> 11.2 us)
+            if (tiny_ring(a.M, a.N, a.K)) return launch<64, 64, 2, 2, FLAGS, RING_NST>(a, s, TINY_RING_SLOTS);
+            return launch<64, 64, 2, 2, FLAGS>(a, s, TINY_SLOTS);
         default: return launch<128, 128, 2, 2, FLAGS>(a, s, 512);
     }
 }
@@ -1214,9 +1220,9 @@ extern "C" int uspace_gemm_plan_k(int M, int N, int K, int producer, int* out) {
     TileChoice tc = (TileChoice)out[0];
     if (producer) tc = producer_tile(tc, N);
     if (refine_small(tc, M, N, K, producer != 0) == TILE_TINY) {
-        const int tn = us_cdiv(N, 64);
-        const Plan p = plan_rows(M, 64, tn, 1024);
-        out[0] = (int)TILE_TINY; out[1] = 0; out[2] = 64; out[3] = 64; out[4] = p.tiles_m; out[5] = tn; out[6] = p.n_strip; out[7] = 1024;
+        const int tn = us_cdiv(N, 64), slots = tiny_ring(M, N, K) ? TINY_RING_SLOTS : TINY_SLOTS;
+        const Plan p = plan_rows(M, 64, tn, slots);
+        out[0] = (int)TILE_TINY; out[1] = 0; out[2] = 64; out[3] = 64; out[4] = p.tiles_m; out[5] = tn; out[6] = p.n_strip; out[7] = slots;
     }
     return USPACE_OK;
 }
