@@ -605,7 +605,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
                 for (int i_ = 0; i_ < TM; ++i_) ta[0][h_][i_] = ta[1][h_][i_];
 #pragma unroll
                 for (int j_ = 0; j_ < TN; ++j_) tw[0][h_][j_] = tw[1][h_][j_];
-                tx[0][h_] = tx[1][h_];
+                if constexpr (XTRA) tx[0][h_] = tx[1][h_];
             }
         }
         // the last NST-1 barriers: nothing left to refill, the NST-2-J younger tiles stay in flight

@@ -432,8 +432,9 @@ __global__ __launch_bounds__(256) void head_pack_kernel(const float* __restrict_
     head_weight_image(ng, nb, dw, db, PD, D, image, image + 2 * D, red, (float*)(image + 4 * D));
 }
 
-// PACKED: `dw` is the image head_pack_kernel wrote (ng / nb / db unused)
-template <int UNR, bool PACKED>
+// PACKED: `dw` is the image head_pack_kernel wrote (ng / nb / db unused).  KSPLIT (few tokens: a wave's two passes over its 16 rows are
+// one latency chain): the four waves of a block share 16 tokens and a quarter of the k range each, partial sums meet in LDS.
+template <int UNR, bool PACKED, bool KSPLIT = false>
 __global__ __launch_bounds__(256) void head_pred_mfma_kernel(const float* __restrict__ tok, int L, int extras,
                                                              const float* __restrict__ ng, const float* __restrict__ nb,
                                                              const float* __restrict__ dw, const float* __restrict__ db,
@@ -457,14 +458,16 @@ __global__ __launch_bounds__(256) void head_pred_mfma_kernel(const float* __rest
     const int npatch = g * g;
     const int total = B * npatch;
     const int fr = lane & 15, fq = lane >> 4;
-    const int idx = (blockIdx.x * 4 + wave) * 16 + fr;
+    const int idx = KSPLIT ? blockIdx.x * 16 + fr : (blockIdx.x * 4 + wave) * 16 + fr;
     const int idc = idx < total ? idx : total - 1;
     const int b = idc / npatch, tp = idc % npatch;
     const float* xr = tok + ((size_t)b * L + extras + tp) * D + fq * 8;
-    const int nk = D >> 5;                                        // 32-wide k steps
+    const int nk_all = D >> 5;                                    // 32-wide k steps
+    const int kbeg = KSPLIT ? wave * (nk_all >> 2) : 0;           // this wave's k steps (KSPLIT: D % 128 == 0)
+    const int nk = KSPLIT ? kbeg + (nk_all >> 2) : nk_all;
     // pass 1: mean
     float sm = 0.f;
-    for (int k0 = 0; k0 < nk; k0 += UNR) {
+    for (int k0 = kbeg; k0 < nk; k0 += UNR) {
         f32x4 xa[UNR], xc[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -478,11 +481,17 @@ __global__ __launch_bounds__(256) void head_pred_mfma_kernel(const float* __rest
     }
     sm += __shfl_xor(sm, 16, 64);
     sm += __shfl_xor(sm, 32, 64);
+    if constexpr (KSPLIT) {
+        if (fq == 0) red[wave * 16 + fr] = sm;
+        __syncthreads();
+        sm = (red[fr] + red[16 + fr]) + (red[32 + fr] + red[48 + fr]);
+        __syncthreads();                                          // red is written again below
+    }
     const float mean = sm / (float)D;
     // pass 2: centred second moment and the projection
     float q = 0.f;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < nk; k0 += UNR) {
+    for (int k0 = kbeg; k0 < nk; k0 += UNR) {
         f32x4 xa[UNR], xc[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -515,6 +524,16 @@ __global__ __launch_bounds__(256) void head_pred_mfma_kernel(const float* __rest
     }
     q += __shfl_xor(q, 16, 64);
     q += __shfl_xor(q, 32, 64);
+    if constexpr (KSPLIT) {
+        __syncthreads();                                          // every wave is done with the weight image: its LDS holds the partial sums now
+        f32x4* pacc = (f32x4*)hsm;
+        pacc[wave * 64 + lane] = acc;
+        if (fq == 0) red[wave * 16 + fr] = q;
+        __syncthreads();
+        if (wave != 0) return;
+        acc = (pacc[lane] + pacc[64 + lane]) + (pacc[128 + lane] + pacc[192 + lane]);
+        q = (red[fr] + red[16 + fr]) + (red[32 + fr] + red[48 + fr]);
+    }
     const float rstd = rsqrtf(q / (float)D + eps);
     if (idx < total) {
         const int ph = tp / g, pwid = tp % g;
@@ -773,8 +792,13 @@ extern "C" int uspace_embed_tokens(const float* img, const float* t, int t_strid
         hipLaunchKernelGGL(embed_kernel, dim3(B * (1 + n_extra)), dim3(256), 0, s, img, t, t_stride, extra, n_extra,
                            time_first, patch_w, patch_b, pos, tok, tok_bf16, C, S, p, D, 1);
         US_CHECK_LAUNCH();
-        hipLaunchKernelGGL(embed_patch16_kernel<TOK>, dim3(B * (g * g / TOK)), dim3(256), 0, s, img, patch_w, patch_b, pos,
-                           tok, tok_bf16, C, S, p, D, L, 1 + n_extra);
+        // a block walks its tokens one after the other: few blocks (small batches) take 4 tokens each instead of 16
+        if (B * (g * g / TOK) < 512 && (g * g) % 4 == 0)
+            hipLaunchKernelGGL(embed_patch16_kernel<4>, dim3(B * (g * g / 4)), dim3(256), 0, s, img, patch_w, patch_b, pos,
+                               tok, tok_bf16, C, S, p, D, L, 1 + n_extra);
+        else
+            hipLaunchKernelGGL(embed_patch16_kernel<TOK>, dim3(B * (g * g / TOK)), dim3(256), 0, s, img, patch_w, patch_b, pos,
+                               tok, tok_bf16, C, S, p, D, L, 1 + n_extra);
     } else {
         hipLaunchKernelGGL(embed_kernel, dim3(B * L), dim3(256), 0, s, img, t, t_stride, extra, n_extra,
                            time_first, patch_w, patch_b, pos, tok, tok_bf16, C, S, p, D, 0);
@@ -832,9 +856,16 @@ int us_output_head_packed(const float* tok, int L, int extras, const float* imag
     if (extras + g * g != L) return USPACE_ERR_ARG;
     const size_t lds = (size_t)64 * D + (64 + 16) * 4;
     static std::atomic<uint64_t> lds_ok{0};
-    US_TRY(us_opt_in_lds((const void*)head_pred_mfma_kernel<8, true>, 140 * 1024, lds_ok));
-    hipLaunchKernelGGL((head_pred_mfma_kernel<8, true>), dim3(us_cdiv(B * g * g, 64)), dim3(256), lds, s, tok, L, extras, nullptr,
-                       nullptr, image, nullptr, scratch, B, C, S, p, D, eps);
+    if (B * g * g <= 4096 && (D & 127) == 0) {      // up to 256 blocks of 16 tokens: k range cut over the waves
+        static std::atomic<uint64_t> lds_ok_k{0};
+        US_TRY(us_opt_in_lds((const void*)head_pred_mfma_kernel<8, true, true>, 140 * 1024, lds_ok_k));
+        hipLaunchKernelGGL((head_pred_mfma_kernel<8, true, true>), dim3(us_cdiv(B * g * g, 16)), dim3(256), lds, s, tok, L, extras, nullptr,
+                           nullptr, image, nullptr, scratch, B, C, S, p, D, eps);
+    } else {
+        US_TRY(us_opt_in_lds((const void*)head_pred_mfma_kernel<8, true>, 140 * 1024, lds_ok));
+        hipLaunchKernelGGL((head_pred_mfma_kernel<8, true>), dim3(us_cdiv(B * g * g, 64)), dim3(256), lds, s, tok, L, extras, nullptr,
+                           nullptr, image, nullptr, scratch, B, C, S, p, D, eps);
+    }
     US_CHECK_LAUNCH();
     const long total = (long)B * C * S * S;
     hipLaunchKernelGGL(conv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, scratch, conv_w, conv_b,
