@@ -278,7 +278,7 @@ def main():
         from uspace_amd.flow_matching_t2i import CNF
     else:
         from uspace_amd.flow_matching import CNF
-    cnf = CNF(net)                                             # product defaults: hipGraph replay of plain evaluations
+    cnf = CNF(net)                                             # product defaults: eager launches (USPACE_UVIT_GRAPH=1: hipGraph replay)
     if os.environ.get("USPACE_BENCH_EAGER") == "1":            # profiling aid: rocprofv3's kernel trace crashes on graph replays
         net.use_graph = False
     B = args.batch

@@ -6,6 +6,7 @@ libs/uvit_t2i.py:193-293 -- part of the ABI) but hold no torch c
 libuspace_hip.so per network evaluation.
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -70,7 +71,11 @@ class UViTBase(nn.Module):
         self._packed = None          # (device, versions, blob)
         self._workspace = {}         # B -> uint8 tensor
         self._delta_cache = {}
-        self.use_graph = True        # replay a captured hipGraph for plain (un-hooked) evaluations
+        # Replay a captured hipGraph for plain (un-hooked) evaluations.  Off by default since round 3: one C call enqueues a whole
+        # evaluation and the kernels take longer to run than to launch at every batch size, so the replay only adds its three small
+        # copies into / out of the graph's static buffers (U-ViT-S at batch 4: 15.14 ms per 20-step solve against 14.84 eager).
+        # ``USPACE_UVIT_GRAPH=1`` or ``net.use_graph = True`` turn it on (a host that cannot keep ahead of the GPU).
+        self.use_graph = os.environ.get("USPACE_UVIT_GRAPH", "0") == "1"
         self._graphs = {}            # (B, device, blob ptr, has ctx, LN-fold mode) -> _GraphEntry (at most _MAX_GRAPHS)
 
     # ------------------------------------------------------------------ parameter tree
