@@ -65,7 +65,16 @@ class CNFBase(nn.Module):
             th = float(t.item())
         else:
             th = float(t)
-        return torch.full((), th, dtype=torch.float32, device=x.device).expand(x.shape[0]), th
+        # a fixed-step solve visits the same times in every solve: keep their device scalars (never written again) instead of one
+        # fill launch per evaluation
+        cache = self.__dict__.setdefault("_t_scalars", {})
+        key = (x.device, th)
+        ts = cache.get(key)
+        if ts is None:
+            if len(cache) >= 1024:
+                cache.clear()
+            ts = cache[key] = torch.full((), th, dtype=torch.float32, device=x.device)
+        return ts.expand(x.shape[0]), th
 
     def _integrate(self, func, y0, t0, t1, ode_kwargs, n_steps=None):
         stats = self.last_stats if self.last_stats is not None else Stats()
