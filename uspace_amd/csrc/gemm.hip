@@ -451,6 +451,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
 #ifndef USPACE_RING_PREFETCH_ALL
 #define USPACE_RING_PREFETCH_ALL 0
 #endif
+#ifndef USPACE_TINY_UNROLL
+#define USPACE_TINY_UNROLL 1
+#endif
     constexpr bool TINYK = NST > 2 && ((BM == 64 && BN == 64) || USPACE_RING_PREFETCH_ALL);
     if constexpr (!TINYK) {
         LOAD_A(af0, smem, 0, c_k0)
@@ -593,6 +596,30 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         }
         int kt = 0, buf = 0;
         T_LOAD(0, smem)
+        // whole turns of the ring with the buffer index a compile-time constant: LDS addresses become instruction offsets (a lone wave
+        // issues an instruction every 3-4 cycles, and the K tile of this form is bound by its instruction count)
+#define KTILE_TC(P, Q, BUFC)                                                                       \
+        {                                                                                          \
+            constexpr int nb_ = ((BUFC) + 1) % NST;                                                \
+            __builtin_amdgcn_s_waitcnt((((NST - 2) * IPT) & 15) | (7 << 4) | (0 << 8) | (((((NST - 2) * IPT) >> 4) & 3) << 14)); \
+            __builtin_amdgcn_s_barrier();                                                          \
+            T_LOAD(Q, smem + nb_ * STAGE_BYTES)                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            stage_a(kt + NST, BUFC);                                                               \
+            stage_w(kt + NST, BUFC);                                                               \
+            T_MMA(P)                                                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            ++kt;                                                                                  \
+        }
+        if constexpr (NST == 4 && USPACE_TINY_UNROLL) {
+            while (kt + 2 * NST - 1 < nk) {       // all four tiles of the turn refill (tile kt+7 exists); buf is 0 before and after
+                KTILE_TC(0, 1, 0)
+                KTILE_TC(1, 0, 1)
+                KTILE_TC(0, 1, 2)
+                KTILE_TC(1, 0, 3)
+            }
+        }
+#undef KTILE_TC
         while (kt + NST + 1 < nk) {
             KTILE_T((NST - 2) * IPT, true, 0, 1)
             KTILE_T((NST - 2) * IPT, true, 1, 0)
