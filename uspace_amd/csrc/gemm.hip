@@ -461,6 +461,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         if constexpr (XTRA) { LOAD_X(xf0, smem, c_k0) }
     }
 
+    // Where the per-K-tile barrier sits: behind all but the last HM/2 row blocks' MFMAs of the tile (the 8 MFMAs left cover the next tile's first
+    // fragment reads), or one step earlier (16 left) for the 256x128 form, whose MFMA phases are half as long (`profiles/r03_gemm_ablation.md` section 24;
+    // for the 256x256 form the earlier barrier is neutral and costs registers)
+#ifndef USPACE_EARLY_BARRIER
+#define USPACE_EARLY_BARRIER (BM == 256 && BN == 128)
+#endif
+    constexpr bool EARLYB = USPACE_EARLY_BARRIER;
 #define KTILE(kt, MORE, MORE2)                                                                     \
     {                                                                                              \
         const char* cur = smem + (kt & 1) * STAGE_BYTES;                                           \
@@ -487,7 +494,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         __builtin_amdgcn_sched_barrier(0);                                                         \
         MMA(af0, wf1, 0, 1, HM)                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        MMA(af1, wf1, 1, 0, HM / 2)                                                                \
+        if constexpr (!EARLYB) { MMA(af1, wf1, 1, 0, HM / 2) }                                     \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         if (MORE) {                                                                                \
             __syncthreads(); /* tile kt+1 landed for everyone; buffer kt&1 is free */              \
@@ -498,6 +505,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
             if constexpr (XTRA) { LOAD_X(xf0, nxt, c_k0) }                                         \
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
+        if constexpr (EARLYB) { MMA(af1, wf1, 1, 0, HM / 2) }                                      \
         MMA(af1, wf1, 1, HM / 2, HM)                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                         \
     }
