@@ -162,17 +162,10 @@ __global__ __launch_bounds__(256) void quick_gelu_kernel(bf16_t* __restrict__ x,
 // ------------------------------------------------------------------------------------------
 // Token assembly. grid = B*L blocks; each block writes one token row of D floats.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ img, const float* __restrict__ t, int t_stride,
-                                                    const float* __restrict__ extra, int n_extra, int time_first,
-                                                    const float* __restrict__ pw, const float* __restrict__ pb,
-                                                    const float* __restrict__ pos, float* __restrict__ tok,
-                                                    bf16_t* __restrict__ tok_bf16, int C, int S, int p, int D,
-                                                    int only_special) {
-    const int g = S / p;
-    const int L = 1 + n_extra + g * g;
-    const int per = only_special ? 1 + n_extra : L;     // tokens of a sample this launch covers (the leading ones)
-    const int b = blockIdx.x / per;
-    const int l = blockIdx.x % per;
+// Time / label / context token l of sample b (the tokens in front of the patch tokens): one block per row.
+__device__ __forceinline__ void embed_special_row(const float* __restrict__ t, int t_stride, const float* __restrict__ extra, int n_extra,
+                                                  int time_first, const float* __restrict__ pos, float* __restrict__ tok,
+                                                  bf16_t* __restrict__ tok_bf16, int b, int l, int L, int D) {
     const int time_pos = time_first ? 0 : n_extra;
     const int extra_pos = time_first ? 1 : 0;
     float* out = tok + ((size_t)b * L + l) * D;
@@ -203,9 +196,40 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ im
             }
             put4(d, v);
         }
-    } else if (l >= extra_pos && l < extra_pos + n_extra && l != time_pos) {
+    } else {
         const float* src = extra + ((size_t)b * n_extra + (l - extra_pos)) * D;
         for (int d = threadIdx.x * 4; d < D; d += blockDim.x * 4) put4(d, *(const f32x4*)(src + d));
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ img, const float* __restrict__ t, int t_stride,
+                                                    const float* __restrict__ extra, int n_extra, int time_first,
+                                                    const float* __restrict__ pw, const float* __restrict__ pb,
+                                                    const float* __restrict__ pos, float* __restrict__ tok,
+                                                    bf16_t* __restrict__ tok_bf16, int C, int S, int p, int D,
+                                                    int only_special) {
+    const int g = S / p;
+    const int L = 1 + n_extra + g * g;
+    const int per = only_special ? 1 + n_extra : L;     // tokens of a sample this launch covers (the leading ones)
+    const int b = blockIdx.x / per;
+    const int l = blockIdx.x % per;
+    const int time_pos = time_first ? 0 : n_extra;
+    const int extra_pos = time_first ? 1 : 0;
+    float* out = tok + ((size_t)b * L + l) * D;
+    bf16_t* outb = tok_bf16 ? tok_bf16 + ((size_t)b * L + l) * D : nullptr;
+    const float* posr = pos + (size_t)l * D;
+    auto put4 = [&](int d, f32x4 v) {   // D % 4 == 0: 16-byte stores
+        v += *(const f32x4*)(posr + d);
+        *(f32x4*)(out + d) = v;
+        if (outb) {
+            uint2 q;
+            q.x = pack_bf2(v[0], v[1]);
+            q.y = pack_bf2(v[2], v[3]);
+            *(uint2*)(outb + d) = q;
+        }
+    };
+    if (l == time_pos || (l >= extra_pos && l < extra_pos + n_extra)) {
+        embed_special_row(t, t_stride, extra, n_extra, time_first, pos, tok, tok_bf16, b, l, L, D);
     } else {
         // PatchEmbed conv k = s = p (libs/uvit.py:171-178): pixels consumed in (c, i, j) order
         __shared__ __attribute__((aligned(16))) float px[64];
@@ -255,11 +279,18 @@ template <int TOK>
 __global__ __launch_bounds__(256) void embed_patch16_kernel(const float* __restrict__ img, const float* __restrict__ pw,
                                                             const float* __restrict__ pb, const float* __restrict__ pos,
                                                             float* __restrict__ tok, bf16_t* __restrict__ tok_bf16,
-                                                            int C, int S, int p, int D, int L, int first_patch) {
+                                                            int C, int S, int p, int D, int L, int first_patch,
+                                                            const float* __restrict__ t, int t_stride, const float* __restrict__ extra,
+                                                            int time_first, int B) {
     __shared__ __attribute__((aligned(16))) float px[TOK][16];
     const int g = S / p;
     const int npatch = g * g;
     const int chunks = npatch / TOK;
+    if ((int)blockIdx.x >= B * chunks) {        // the blocks behind the patch blocks: one special token each (one launch for all rows)
+        const int idx = blockIdx.x - B * chunks;
+        embed_special_row(t, t_stride, extra, first_patch - 1, time_first, pos, tok, tok_bf16, idx / first_patch, idx % first_patch, L, D);
+        return;
+    }
     const int b = blockIdx.x / chunks;
     const int t0 = (blockIdx.x % chunks) * TOK;            // first patch of this block
     {
@@ -788,17 +819,15 @@ extern "C" int uspace_embed_tokens(const float* img, const float* t, int t_strid
     hipStream_t s = (hipStream_t)stream;
     constexpr int TOK = 16;
     if (C * p * p == 16 && (g * g) % TOK == 0) {
-        // time / label / context tokens by the per-token kernel, patch tokens by the register-weight kernel
-        hipLaunchKernelGGL(embed_kernel, dim3(B * (1 + n_extra)), dim3(256), 0, s, img, t, t_stride, extra, n_extra,
-                           time_first, patch_w, patch_b, pos, tok, tok_bf16, C, S, p, D, 1);
-        US_CHECK_LAUNCH();
+        // patch tokens by the register-weight kernel; its trailing B * (1 + n_extra) blocks write the time / label / context tokens
         // a block walks its tokens one after the other: few blocks (small batches) take 4 tokens each instead of 16
+        const int nsp = B * (1 + n_extra);
         if (B * (g * g / TOK) < 512 && (g * g) % 4 == 0)
-            hipLaunchKernelGGL(embed_patch16_kernel<4>, dim3(B * (g * g / 4)), dim3(256), 0, s, img, patch_w, patch_b, pos,
-                               tok, tok_bf16, C, S, p, D, L, 1 + n_extra);
+            hipLaunchKernelGGL(embed_patch16_kernel<4>, dim3(B * (g * g / 4) + nsp), dim3(256), 0, s, img, patch_w, patch_b, pos,
+                               tok, tok_bf16, C, S, p, D, L, 1 + n_extra, t, t_stride, extra, time_first, B);
         else
-            hipLaunchKernelGGL(embed_patch16_kernel<TOK>, dim3(B * (g * g / TOK)), dim3(256), 0, s, img, patch_w, patch_b, pos,
-                               tok, tok_bf16, C, S, p, D, L, 1 + n_extra);
+            hipLaunchKernelGGL(embed_patch16_kernel<TOK>, dim3(B * (g * g / TOK) + nsp), dim3(256), 0, s, img, patch_w, patch_b, pos,
+                               tok, tok_bf16, C, S, p, D, L, 1 + n_extra, t, t_stride, extra, time_first, B);
     } else {
         hipLaunchKernelGGL(embed_kernel, dim3(B * L), dim3(256), 0, s, img, t, t_stride, extra, n_extra,
                            time_first, patch_w, patch_b, pos, tok, tok_bf16, C, S, p, D, 0);
