@@ -714,3 +714,48 @@ def test_built_library_matches_the_sources_in_the_tree():
     assert old["library_sha256"] == now["library_sha256"], "libuspace_hip.so changed since build() stamped it"
     assert old["sources"] == now["sources"], [k for k in now["sources"] if old["sources"].get(k) != now["sources"][k]]
     assert "uspace_amd/csrc/gemm.hip" in now["sources"]
+
+
+def test_ring_form_tiny_launches_plan_for_two_workgroups_per_cu():
+    """The 64x64 ring form holds 66-74 KiB of LDS: 512 workgroups per round, and a remainder of a few rows is a strip, not a second
+    round (fc1 of U-ViT-L at 2 x 257 rows: 8 x 64 workgroups + one strip instead of 9 x 64).  The two-stage form keeps 1024."""
+    from uspace_amd import _hip
+    L = _hip.lib()
+    out = (ctypes.c_int * 8)()
+    assert L.uspace_gemm_plan_k(514, 4096, 1024, 0, out) == 0          # 16 K tiles: the ring form
+    assert list(out)[:1] == [5] and (out[2], out[3]) == (64, 64)
+    assert (out[4], out[5], out[6], out[7]) == (8, 64, 1, 512)
+    assert L.uspace_gemm_plan_k(1028, 2048, 512, 0, out) == 0          # 8 K tiles, 544 tiles: the two-stage form
+    assert out[0] == 5 and (out[4], out[5], out[7]) == (17, 32, 1024)
+    assert L.uspace_gemm_plan_k(1028, 512, 512, 1, out) == 0           # proj of U-ViT-S at 4 x 257 rows: ring, one round either way
+    assert out[0] == 5 and (out[4], out[5], out[6], out[7]) == (17, 8, 0, 512)
+
+
+def test_cnf_reuses_the_device_scalars_of_its_time_grid():
+    """CNFBase._timesteps: one 0-dim tensor per distinct time (never written again), expanded per call -- no fill launch per evaluation."""
+    from uspace_amd.flow_matching import CNF
+
+    class Net(torch.nn.Module):
+        def forward(self, x, t, y=None, **kw):
+            return x, None
+
+    cnf = CNF(Net())
+    x = torch.zeros(3, 4, 2, 2)
+    a, th = cnf._timesteps(0.25, x)
+    b, _ = cnf._timesteps(torch.tensor(0.25), x)
+    c, _ = cnf._timesteps(0.5, x)
+    assert th == 0.25 and a.shape == (3,) and a.stride(0) == 0 and float(a[0]) == 0.25 and float(c[2]) == 0.5
+    assert a.data_ptr() == b.data_ptr() != c.data_ptr()
+    per_sample = torch.tensor([0.1, 0.2, 0.3])
+    d, thd = cnf._timesteps(per_sample, x)
+    assert d is per_sample and thd is None
+
+
+def test_graph_replay_is_opt_in(monkeypatch):
+    from uspace_amd.tools.utils_uvit import get_nnet
+    kw = dict(img_size=8, patch_size=2, in_chans=4, embed_dim=64, depth=2, num_heads=1, mlp_ratio=4, qkv_bias=False,
+              mlp_time_embed=False, num_classes=-1)
+    monkeypatch.delenv("USPACE_UVIT_GRAPH", raising=False)
+    assert get_nnet("uvit", **kw).use_graph is False
+    monkeypatch.setenv("USPACE_UVIT_GRAPH", "1")
+    assert get_nnet("uvit", **kw).use_graph is True
