@@ -514,6 +514,8 @@ def test_layernorm_folded_through_gemms(hip, M, D, Kp, N2):
     (4 * 257, 512, 2048, "producer"),       # fc2 of the in-blocks: 32 K tiles through the four-stage ring, fused producer epilogue
     (4 * 257, 512, 2048, "bias_resid_f32_bf16"),   # fc2 of the mid / out blocks
     (1030, 256, 1024, "bias_gelu_bf16"),    # ring form, ragged rows (strip) and 16 K tiles
+    (2 * 257, 4096, 1024, "bias_gelu_bf16"),  # fc1 of U-ViT-L at batch 2: ring form planned for 512 workgroups = 8 x 64 tiles + a 2-row strip
+    (2 * 257 + 40, 4096, 1024, "bias_resid_f32_bf16"),   # ... three strips of 16 rows (42 remainder rows)
 ])
 def test_gemm_64x64_tile_form(hip, M, N, K, kind):
     """Launches whose 128x128 tiling would fill 160 workgroups or fewer run as 64x64 tiles (round 3, `refine_small` in gemm.hip;
