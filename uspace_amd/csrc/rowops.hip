@@ -599,6 +599,47 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
     out[i] = s;
 }
 
+// The same for a compile-time channel count (every reference config: C = 4): the 36 taps are unrolled, their loads issued together (clamped
+// addresses, out-of-range taps dropped by a select) and added in the order of the loop above -- bit-identical, without its chain of dependent loads.
+template <int CT>
+__global__ __launch_bounds__(256) void conv3x3_fixed_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ out, int B, int S) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)B * CT * S * S;
+    if (i >= total) return;
+    const int xx = i % S, yy = (i / S) % S, co = (i / ((long)S * S)) % CT, b = i / ((long)S * S * CT);
+    float xv[CT][3][3], wv[CT][3][3];
+#pragma unroll
+    for (int ci = 0; ci < CT; ++ci)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int y2 = min(max(yy + dy - 1, 0), S - 1), x2 = min(max(xx + dx - 1, 0), S - 1);
+                xv[ci][dy][dx] = in[(((size_t)b * CT + ci) * S + y2) * S + x2];
+                wv[ci][dy][dx] = w[((co * CT + ci) * 3 + dy) * 3 + dx];
+            }
+    float s = bias[co];
+#pragma unroll
+    for (int ci = 0; ci < CT; ++ci)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int y2 = yy + dy - 1, x2 = xx + dx - 1;
+                const float t = s + wv[ci][dy][dx] * xv[ci][dy][dx];
+                s = (y2 < 0 || y2 >= S || x2 < 0 || x2 >= S) ? s : t;
+            }
+    out[i] = s;
+}
+
+inline void launch_conv3x3(const float* in, const float* w, const float* bias, float* out, int B, int C, int S, hipStream_t s) {
+    const long total = (long)B * C * S * S;
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (C == 4) hipLaunchKernelGGL(conv3x3_fixed_kernel<4>, grid, block, 0, s, in, w, bias, out, B, S);
+    else hipLaunchKernelGGL(conv3x3_kernel, grid, block, 0, s, in, w, bias, out, B, C, S);
+}
+
 // x[b, i] += scale_b * delta[i] (scale_b = scale * row_scale[b] when row_scale != NULL); optional bf16 copy
 // refresh. per_sample % 4 == 0.
 __global__ __launch_bounds__(256) void add_bcast_kernel(float* __restrict__ x, bf16_t* __restrict__ xb,
@@ -858,9 +899,7 @@ extern "C" int uspace_output_head(const float* tok, int L, int extras, const flo
     else if (D <= 2048) hipLaunchKernelGGL(head_pred_kernel<8>, hgrid, hblock, 0, s, tok, L, extras, norm_g, norm_b, dec_w, dec_b, scratch, B, C, S, p, D, eps);
     else return USPACE_ERR_ARG;
     US_CHECK_LAUNCH();
-    const long total = (long)B * C * S * S;
-    hipLaunchKernelGGL(conv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, scratch, conv_w, conv_b,
-                       out, B, C, S);
+    launch_conv3x3(scratch, conv_w, conv_b, out, B, C, S, s);
     US_CHECK_LAUNCH();
     return USPACE_OK;
 }
@@ -896,9 +935,7 @@ int us_output_head_packed(const float* tok, int L, int extras, const float* imag
                            nullptr, image, nullptr, scratch, B, C, S, p, D, eps);
     }
     US_CHECK_LAUNCH();
-    const long total = (long)B * C * S * S;
-    hipLaunchKernelGGL(conv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, scratch, conv_w, conv_b,
-                       out, B, C, S);
+    launch_conv3x3(scratch, conv_w, conv_b, out, B, C, S, s);
     US_CHECK_LAUNCH();
     return USPACE_OK;
 }
