@@ -58,8 +58,43 @@ struct GemmArgs {
 };
 
 constexpr int BK = 64;           // bf16 elements per K step (128 B per LDS row)
+
+// Measurement switches.  The A/B and ablation builds behind `profiles/r0*_gemm_ablation.md` exist only under -DUSPACE_LAB=1, which
+// `tools/lab/build_variant.sh` passes and `csrc/Makefile` never does (it builds with -DUSPACE_LAB=0 -Werror=undef): a product build
+// that names one of them stops here, and the two switches that produce wrong results on purpose (NOSTORE, NOEPI) cannot reach it.
+#ifndef USPACE_LAB
+#define USPACE_LAB 0
+#endif
+#if !USPACE_LAB
+#if defined(USPACE_ABLATE_NOSTORE) || defined(USPACE_ABLATE_NOEPI) || defined(USPACE_ABLATE_NOGELU) || defined(USPACE_DMA_FLAT) || \
+    defined(USPACE_RING_PREFETCH_ALL) || defined(USPACE_TINY_UNROLL) || defined(USPACE_EARLY_BARRIER) || defined(USPACE_TALL_COST)
+#error "measurement switches need -DUSPACE_LAB=1 (tools/lab/build_variant.sh); the product build takes none"
+#endif
+#define USPACE_ABLATE_NOSTORE 0
+#define USPACE_ABLATE_NOEPI 0
+#define USPACE_ABLATE_NOGELU 0
+#else
+#ifndef USPACE_ABLATE_NOSTORE
+#define USPACE_ABLATE_NOSTORE 0  /* 1: the epilogue computes and stores nothing (wrong results; timing only) */
+#endif
+#ifndef USPACE_ABLATE_NOEPI
+#define USPACE_ABLATE_NOEPI 0    /* 1: the kernel ends behind its K loop (wrong results; timing only) */
+#endif
+#ifndef USPACE_ABLATE_NOGELU
+#define USPACE_ABLATE_NOGELU 0   /* 1: fc1 without its activation (wrong results; timing only) */
+#endif
+#endif
 #ifndef USPACE_TALL_COST
 #define USPACE_TALL_COST 0.60    // one round of 256x128 tiles in units of a round of 256x256 tiles (measured, r02_gemm_ablation.md)
+#endif
+#ifndef USPACE_DMA_FLAT
+#define USPACE_DMA_FLAT 0        // 1: the round-2 flat global_load_lds form (A/B measurements)
+#endif
+#ifndef USPACE_RING_PREFETCH_ALL
+#define USPACE_RING_PREFETCH_ALL 0
+#endif
+#ifndef USPACE_TINY_UNROLL
+#define USPACE_TINY_UNROLL 1
 #endif
 constexpr int ROW_BYTES = 128;
 
@@ -250,9 +285,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
     // form global_load_lds needed a 64-bit VALU add into the same address register pair before every instruction -- the zero
     // extension of the offsets was hoisted out of the loop, so the scalar-base addressing mode never matched -- and each add had to
     // wait for the previous instruction to have read that pair: 80-130 cycles per DMA instruction, `profiles/r03_gemm_ablation.md`.)
-#ifndef USPACE_DMA_FLAT
-#define USPACE_DMA_FLAT 0       /* 1: the round-2 flat global_load_lds form (A/B measurements) */
-#endif
     auto dma16 = [&](const char* ubase, const __amdgpu_buffer_rsrc_t& rs, uint32_t voff, char* lds) {
         if constexpr (USPACE_DMA_FLAT != 0)
             __builtin_amdgcn_global_load_lds((const US_GLB void*)(ubase + voff), (US_LDS void*)lds, 16, 0, 0);
@@ -448,12 +480,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         }
     }
     // 64 x 64 tiles in the ring form keep the fragments of a whole K tile in registers, fetched one tile ahead (see KTILE_T below)
-#ifndef USPACE_RING_PREFETCH_ALL
-#define USPACE_RING_PREFETCH_ALL 0
-#endif
-#ifndef USPACE_TINY_UNROLL
-#define USPACE_TINY_UNROLL 1
-#endif
     constexpr bool TINYK = NST > 2 && ((BM == 64 && BN == 64) || USPACE_RING_PREFETCH_ALL);
     if constexpr (!TINYK) {
         LOAD_A(af0, smem, 0, c_k0)
@@ -704,7 +730,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         return v;
     };
     auto emit_post = [&](const f32x4& v, int m, int n) {
-#ifdef USPACE_ABLATE_NOSTORE
+#if USPACE_ABLATE_NOSTORE
         asm volatile("" ::"v"(v));
         return;
 #endif
@@ -780,7 +806,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         }
     };
     const bool interior = (m0 + BM <= m_lim) && (n0 + BN <= g.N);   // workgroup-uniform
-#ifdef USPACE_ABLATE_NOEPI
+#if USPACE_ABLATE_NOEPI
     {
         float sacc = 0.f;
 #pragma unroll
@@ -801,7 +827,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
             f32x4 v[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j) v[j] = emit_pre(acc[i][j], bias4[j], cs4[LN_IN ? j : 0]);
-#ifndef USPACE_ABLATE_NOGELU
+#if !USPACE_ABLATE_NOGELU
             if constexpr (FLAGS & USPACE_EPI_GELU) gelu_erf_batch<TN>(v);
 #endif
             uint2 pk[TN], pc[TN];
@@ -825,7 +851,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
                 ps1 = (s1v[0] + s1v[1]) + (s1v[2] + s1v[3]);
                 ps2 = (s2v[0] + s2v[1]) + (s2v[2] + s2v[3]);
             }
-#ifndef USPACE_ABLATE_NOSTORE
+#if !USPACE_ABLATE_NOSTORE
 #pragma unroll
             for (int j = 0; j < TN; j += 2) {
                 if constexpr (FLAGS & USPACE_EPI_OUT_BF16) *(uint4*)(g.out_bf16 + (size_t)m * g.ld_bf16 + nw + j * 16) = widen_pair(pk[j], pk[j + 1]);
