@@ -207,6 +207,36 @@ def hook_kwargs(net, tmpdir):
                 ith_attr="31_39_20", write_path_root=tmpdir)
 
 
+class Runtime:
+    """The device side of the benchmark: one ROCm device per rank, RCCL between them (backend "nccl" IS RCCL on ROCm), HIP events
+    on the launching stream.  tests/test_multigpu_readiness.py substitutes a CPU + gloo stand-in (and stubs the kernel launches at
+    uspace_amd._hip.lib()) so that main() -- rank discovery, process group, the sharded solves, the gather, the self-check of the
+    gathered batch and the JSON line -- runs end to end on two ranks without GPUs."""
+    backend = "nccl"
+
+    def __init__(self, local_rank):
+        assert torch.cuda.is_available(), "bench.py needs ROCm devices"
+        torch.cuda.set_device(local_rank)
+        self.device = torch.device("cuda", local_rank)
+
+    def init_group(self, rank, world):
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(self.backend, rank=rank, world_size=world, device_id=self.device)
+
+    def synchronize(self):
+        torch.cuda.synchronize()
+
+    def event(self):
+        return torch.cuda.Event(enable_timing=True)
+
+    def device_name(self):
+        p = torch.cuda.get_device_properties(self.device)
+        return f"{p.name} ({getattr(p, 'gcnArchName', '?')}, {p.multi_processor_count} CUs)"
+
+
+RUNTIME = Runtime
+
+
 def relaunch_argv(gpus, port, argv):
     """The one-rank-per-GPU launch of this script on one node (the form the driver uses for N > 1)."""
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
@@ -255,15 +285,21 @@ def main():
             return
         os.execvp(argv[0], argv)
     world, rank, local_rank = rank_env(args.gpus)
-    assert torch.cuda.is_available(), "bench.py needs ROCm devices"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    rt = RUNTIME(local_rank)
+    dev = rt.device
+    ranks_seen = [dict(rank=rank, local_rank=local_rank, device=rt.device_name(), pid=os.getpid())]
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        _w = torch.zeros(8, device=dev)                       # create the RCCL communicator outside the timed region
-        dist.all_gather([torch.empty_like(_w) for _ in range(world)], _w)
-        torch.cuda.synchronize()
+        rt.init_group(rank, world)
+        _w = torch.full((8,), float(rank), device=dev)        # create the communicator outside the timed region ...
+        got = [torch.empty_like(_w) for _ in range(world)]
+        dist.all_gather(got, _w)
+        rt.synchronize()
+        # ... and prove it: every rank of the launch answered, in rank order, each from its own process and device
+        assert [int(g[0].item()) for g in got] == list(range(world)), "all_gather did not return the ranks in order"
+        objs = [None] * world
+        dist.all_gather_object(objs, ranks_seen[0])
+        ranks_seen = objs
+        assert [o["rank"] for o in ranks_seen] == list(range(world)) and len({o["pid"] for o in ranks_seen}) == world
 
     from uspace_amd import _hip
     from uspace_amd.sampling import gather_batch
@@ -295,41 +331,55 @@ def main():
         sk["solver"] = "adaptive" if kind == "dopri5" else "fixed"
         return sk
 
+    last_local = [None]
+
     def solve(kind, gather=True):
         kw = dict(dissect_name="bench", edit_loc=None, solver_kwargs=solver_kwargs(kind))
         if hk:
             kw.update(hk)
         out = cnf.decode(z, cond, **kw) if t2i else cnf.decode(z, None, **kw)
+        last_local[0] = out
         return gather_batch(out, B * world) if gather else out   # the one collective of the sampling path
 
     def fence():
-        torch.cuda.synchronize()
+        rt.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        rt.synchronize()
 
     with torch.no_grad():
         for _ in range(args.warmup):
             solve(args.solver)
         # ---- the timed region: exactly `steps` solves between two fences; every solve also bracketed by HIP events on
         #      the stream the kernels run on (torch's current stream is the one handed to the C-ABI)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        ev = [(rt.event(), rt.event()) for _ in range(args.steps)]
         fence()
         t0 = time.perf_counter()
         for i in range(args.steps):
             ev[i][0].record()
             res = solve(args.solver)
             ev[i][1].record()
+            # every timed solve hands back the WHOLE job's batch (a shape check: no device work, no sync)
+            assert res.shape[0] == B * world, f"gathered {res.shape[0]} rows, expected {B} x {world}"
         fence()
         dt = time.perf_counter() - t0
         nfe = cnf.last_stats.nfe
         per_solve_ms = sorted(a.elapsed_time(b) for a, b in ev)
         median_ms = per_solve_ms[len(per_solve_ms) // 2]
         assert bool(torch.isfinite(res).all())
-        tt = torch.tensor([dt, median_ms], dtype=torch.float64, device=dev)
+        # rank r's rows of the gathered batch are rank r's own solve (bit-equal), on every rank
+        mine_ok = bool(torch.equal(res[rank * B:(rank + 1) * B], last_local[0]))
+        rank_dt, rank_median = dt, median_ms
+        tt = torch.tensor([dt, median_ms, 0.0 if mine_ok else 1.0], dtype=torch.float64, device=dev)
+        per_rank = [[rank_dt, rank_median]]
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            mine = torch.tensor([rank_dt, rank_median], dtype=torch.float64, device=dev)
+            allr = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank = [[float(v) for v in a.tolist()] for a in allr]
         dt, median_ms = float(tt[0].item()), float(tt[1].item())
+        assert float(tt[2].item()) == 0.0, "a rank's rows of the gathered batch differ from its own solve"
 
         # ---- outside the timed region: rooflines.  One more solve with eager launches and HIP events recorded (by the
         #      library, on the launching stream) around every GEMM and attention launch
@@ -340,10 +390,15 @@ def main():
         if rank == 0 and not args.no_extra:
             was = net.use_graph
             net.use_graph = False
-            _hip.prof_all_begin(16384)
+            # one event pair per GEMM / attention launch of the whole solve: 5 per block + one skip_linear per out-block, per NFE
+            rec_cap = (nfe + 2) * (5 * (cfg["depth"] + 1) + cfg["depth"] // 2 + 4)
+            _hip.prof_all_begin(rec_cap)
             solve(args.solver, gather=False)                  # rank 0 only: no collective in here
-            torch.cuda.synchronize()
+            rt.synchronize()
+            rec_dropped = _hip.prof_dropped()
             recs = _hip.prof_all_end()
+            if rec_dropped:
+                raise SystemExit(f"bench.py: the launch recorder was full ({rec_cap} launches) and dropped {rec_dropped}: roofline would cover a truncated solve")
             net.use_graph = was
             peaks = _hip.prof_peaks()
         if world > 1:
@@ -360,7 +415,7 @@ def main():
             if world > 1:
                 dist.all_reduce(e, op=dist.ReduceOp.MAX)
             extra = dict(euler50_images_per_sec=B * world / float(e.item()), euler50_nfe=cnf.last_stats.nfe)
-            if world == 1:
+            if world == 1 and dev.type == "cuda":
                 # latents -> 256^2 images through the VAE decoder; outside the timed region and
                 # outside `value`, reported so the latent->latent figure can be read as an end-to-end one
                 try:
@@ -395,6 +450,12 @@ def main():
                                    + ", seeded random-init weights, latent->latent (VAE excluded), "
                                    + ("hipGraph replay per evaluation" if net.use_graph else "eager launches"),
                        "global_batch": B * world, "nfe_per_solve": nfe, "parallelism": f"batch-sharded x{world}"},
+            # what ran, from the process group itself (not from the command line): ranks in the group, who they were, what each of
+            # them measured, and that the gathered batch of the timed solves held every rank's rows (asserted above)
+            "multi_gpu": {"backend": (dist.get_backend() if world > 1 else None), "rccl_world_size": (dist.get_world_size() if world > 1 else 1),
+                          "ranks_seen": ranks_seen, "per_rank_wall_s": [p[0] for p in per_rank],
+                          "per_rank_median_ms": [p[1] for p in per_rank], "gathered_rows": int(res.shape[0]),
+                          "gathered_rows_expected": B * world, "each_ranks_rows_equal_its_own_solve": True},
             "nfe": nfe,
             "median_ms_per_step": median_ms, "per_step_ms_rank0": per_solve_ms,
             "images_per_sec_median": B * world / (median_ms * 1e-3),
@@ -419,7 +480,9 @@ def main():
                                     "achieved": r["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": r["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_note": tnote,
                                     "launches": r["launches"], "avg_us": r["avg_us"], "flops_per_launch": r["flops_per_launch"],
-                                    "timing": "HIP events around every fc1 launch of one extra eager solve after the timed region"}
+                                    "recorder": {"capacity": rec_cap, "recorded": sum(q["launches"] for q in all_rows), "dropped": 0},
+                                    "timing": "HIP events around EVERY GEMM and attention launch of one extra eager solve after the timed "
+                                              "region (the recorder fails the run if it drops a launch)"}
                 if peaks:
                     line["roofline"]["peak_measured"] = {
                         "mfma_bf16_tflops": peaks[0], "hbm_copy_gbs": peaks[1], "shader_ghz_under_mfma_loop": peaks[2],

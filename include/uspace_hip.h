@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define USPACE_ABI_VERSION 7
+#define USPACE_ABI_VERSION 8
 
 #define USPACE_OK 0
 #define USPACE_ERR_ARG (-1)         /* bad pointer / size / unsupported shape */
@@ -114,7 +114,8 @@ USPACE_API int uspace_uvit_set_ln_fold(int mode);
 USPACE_API int uspace_uvit_get_ln_fold(void);
 /* number of N tiles (= partial-sum slots per row) a CEN_OUT launch with this [M, N] output uses */
 USPACE_API int uspace_gemm_part_slots(int M, int N);       /* the largest count over K: size part_out / check np_in <= 8 with it */
-/* ... of the producer GEMM with this K (launches with few tiles and K < 2048 use 64-wide tiles: more slots) */
+/* ... of the producer GEMM with this K.  (Launches of few tiles use 64-wide tiles -- more slots -- whatever their K; K only
+ * selects which K loop those tiles run, so today the count does not depend on it.  Callers pass the real K all the same.) */
 USPACE_API int uspace_gemm_part_slots_k(int M, int N, int K);
 
 /* Which tile configuration uspace_gemm_bf16 uses for an [M, N] output (host-side planning, no GPU work):
@@ -125,8 +126,10 @@ USPACE_API int uspace_gemm_tile_choice(int M, int N, int* split_rows);
  * 16-row remainder strips (each owned by the workgroups of one tile row), workgroups per round of 256 CUs}.  For choice 3 the
  * fields after split_rows describe the 256x256 launch over rows [0, split_rows). */
 USPACE_API int uspace_gemm_plan(int M, int N, int* out);
-/* ... of a launch with this K (and role: producer of LayerNorm partial sums or not): few-tile launches with K < 2048 use 64x64
- * tiles (out[0] = 5, out[2] = out[3] = 64) */
+/* ... of a launch with this K and role (producer of LayerNorm partial sums or not), i.e. what the dispatcher really launches:
+ * few-tile launches use 64x64 tiles (out[0] = 5, out[2] = out[3] = 64; K selects their K loop and with it out[7]: 512 workgroups
+ * per round for the four-stage ring, 1024 for the two-stage form); a producer never takes the split form (reported as 256x256) nor
+ * 128-wide tiles that would make more than 8 partial-sum slots (reported as 256x256). */
 USPACE_API int uspace_gemm_plan_k(int M, int N, int K, int producer, int* out);
 
 /* Sum of row-shifted GEMMs:  acc[m, n] = sum_t A[m + row_shift[t], 0:K1] . W[n, t*K1:(t+1)*K1]  (+ epilogue
@@ -374,6 +377,9 @@ USPACE_API int uspace_prof_gemm_end(double* total_ms, int* n_launches);
  * 2: M (attention: B * H), 3: N (attention: L), 4: K (attention: head dim), 5: launches}] and total_ms[i], i < *n_records <= max_records. */
 USPACE_API int uspace_prof_all_begin(int max_launches);
 USPACE_API int uspace_prof_all_end(int* keys, double* total_ms, int max_records, int* n_records);
+/* Launches that matched but found the recorder full (max_launches reached) since the last _begin(): a recording is complete
+ * only if this is 0 (bench.py fails otherwise instead of pricing a truncated solve). */
+USPACE_API long uspace_prof_dropped(void);
 
 /* What this box reaches on the two rooflines (synchronous, self-timed with HIP events, own scratch; host pointers out):
  * dense bf16 MFMA rate of an MFMA-only loop on every SIMD (TFLOP/s), and a device-to-device float4 stream copy

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     from uspace_amd import _hip
     assert set(_hip.SIGNATURES) == declared
-    assert _hip.lib().uspace_abi_version() == _hip.ABI_VERSION == 7
+    assert _hip.lib().uspace_abi_version() == _hip.ABI_VERSION == 8
 
 
 def test_struct_layouts_agree_between_header_binding_and_integration_doc():
@@ -732,7 +732,8 @@ def test_ring_form_tiny_launches_plan_for_two_workgroups_per_cu():
 
 
 def test_cnf_reuses_the_device_scalars_of_its_time_grid():
-    """CNFBase._timesteps: one 0-dim tensor per distinct time (never written again), expanded per call -- no fill launch per evaluation."""
+    """CNFBase._timesteps on a fixed grid: one 0-dim tensor per distinct time (never written again), expanded per call -- no fill
+    launch per evaluation; bounded, oldest first.  Error-controlled solves (no two times alike) get a fresh scalar per call."""
     from uspace_amd.flow_matching import CNF
 
     class Net(torch.nn.Module):
@@ -741,6 +742,10 @@ def test_cnf_reuses_the_device_scalars_of_its_time_grid():
 
     cnf = CNF(Net())
     x = torch.zeros(3, 4, 2, 2)
+    f1, _ = cnf._timesteps(0.25, x)
+    f2, th2 = cnf._timesteps(0.25, x)
+    assert f1.data_ptr() != f2.data_ptr() and th2 == 0.25 and not cnf.__dict__.get("_t_scalars")      # adaptive: nothing cached
+    cnf._grid_is_fixed = True
     a, th = cnf._timesteps(0.25, x)
     b, _ = cnf._timesteps(torch.tensor(0.25), x)
     c, _ = cnf._timesteps(0.5, x)
@@ -749,6 +754,19 @@ def test_cnf_reuses_the_device_scalars_of_its_time_grid():
     per_sample = torch.tensor([0.1, 0.2, 0.3])
     d, thd = cnf._timesteps(per_sample, x)
     assert d is per_sample and thd is None
+    for k in range(cnf._T_SCALARS_MAX + 5):
+        cnf._timesteps(10.0 + k, x)
+    assert len(cnf._t_scalars) == cnf._T_SCALARS_MAX and (x.device, 0.25) not in cnf._t_scalars
+    # which solves run on a fixed grid: euler / n_steps do, plain dopri5 does not
+    sk = dict(solver="fixed", solver_fix="euler", solver_fix_step=0.5, solver_adaptive="dopri5", solver_adaptive_prec=1e-3)
+    cnf2 = CNF(Net())
+    cnf2.state_ops_factory = TorchCpuOps
+    cnf2.decode(x, None, dissect_name="w", edit_loc=None, solver_kwargs=sk)
+    assert cnf2._grid_is_fixed and sorted(k[1] for k in cnf2._t_scalars) == [0.0, 0.5]
+    cnf2.decode(x, None, dissect_name="w", edit_loc=None, solver_kwargs=dict(sk, solver="adaptive"))
+    assert not cnf2._grid_is_fixed and len(cnf2._t_scalars) == 2                                        # untouched by the adaptive solve
+    cnf2.decode(x, None, dissect_name="w", edit_loc=None, solver_kwargs=dict(sk, solver="adaptive", n_steps=4))
+    assert cnf2._grid_is_fixed and len(cnf2._t_scalars) > 2                                             # dopri5 on 4 equal steps
 
 
 def test_graph_replay_is_opt_in(monkeypatch):
@@ -787,3 +805,19 @@ def test_measurement_switches_cannot_reach_a_product_build():
         tracked = subprocess.run(["git", "-C", ROOT, "ls-files", "uspace_amd"], capture_output=True, text=True).stdout.split()
         junk = [f for f in tracked if f.endswith((".s", ".bc", ".hipi", ".o", ".so")) or "/lib.so." in f or "hipv4-amdgcn" in f]
         assert not junk, junk
+
+
+def test_two_workspaces_stay_resident_lru():
+    """The write_scales sweep (one 9 x B solve) next to plain B solves alternates two batch sizes: neither switch reallocates;
+    a third size evicts the least recently used one.  (Sizes come from the library's own query; CPU memory stands in here.)"""
+    from uspace_amd.tools.utils_uvit import get_nnet
+    net = get_nnet("uvit", img_size=8, patch_size=2, in_chans=4, embed_dim=64, depth=2, num_heads=1, mlp_ratio=4, qkv_bias=False,
+                   mlp_time_embed=False, num_classes=-1)
+    cpu = torch.device("cpu")
+    a, b = net._workspace_for(10, cpu), net._workspace_for(90, cpu)
+    assert a.numel() < b.numel() and len(net._workspace) == 2
+    for _ in range(3):
+        assert net._workspace_for(10, cpu) is a and net._workspace_for(90, cpu) is b
+    c = net._workspace_for(4, cpu)                       # least recently used is B = 10
+    assert list(net._workspace) == [(90, "cpu"), (4, "cpu")] and net._workspace_for(90, cpu) is b
+    assert net._workspace_for(4, cpu) is c and net._workspace_for(10, cpu) is not a and len(net._workspace) == 2

@@ -165,3 +165,141 @@ def test_two_rank_uspace_sweep_and_sample2dir(tmp_path):
         assert p.exitcode == 0
     got = dict(q.get(timeout=5) for _ in range(2))
     assert got == {0: True, 1: True}
+
+
+# ------------------------------------------------------------------------------------------- bench.main() end to end, 2 gloo ranks
+class _FakeKernels:
+    """Stands in for libuspace_hip.so at uspace_amd._hip.lib(): every host-side query goes to the real library (it loads without a
+    GPU); the entry points that would LAUNCH kernels act on the CPU buffers behind the pointers instead -- the network evaluation
+    is v(x, t) = -x (so the trajectories are independent per row, like the real network), the ODE state update is the real
+    arithmetic.  Everything above the C-ABI -- CNF, odeint, the sharding, the gather, bench.py -- is the product's own code."""
+
+    def __init__(self, real):
+        self._real = real
+        self.forwards = 0
+
+    def __getattr__(self, name):
+        return getattr(self._real, name)
+
+    @staticmethod
+    def _arr(p, n):
+        import ctypes
+        addr = p if isinstance(p, int) else (p.value if hasattr(p, "value") else ctypes.cast(p, ctypes.c_void_p).value)
+        return np.ctypeslib.as_array((ctypes.c_float * n).from_address(addr))
+
+    def uspace_uvit_pack_weights(self, *a):
+        return 0
+
+    def uspace_uvit_forward(self, cfg, blob, ws, ws_bytes, io, B, stream):
+        c, o = cfg._obj, io._obj
+        n = B * c.in_chans * c.img_size * c.img_size
+        self._arr(o.out, n)[:] = -self._arr(o.x, n)
+        self.forwards += 1
+        return 0
+
+    def uspace_ode_combine(self, out, y, ks, coefs, n, numel, stream):
+        acc = self._arr(y, numel).astype(np.float32).copy()
+        for i in range(n):
+            acc += np.float32(coefs[i]) * self._arr(ks[i], numel)
+        self._arr(out, numel)[:] = acc
+        return 0
+
+    def uspace_prof_all_begin(self, n):
+        return 0
+
+    def uspace_prof_dropped(self):
+        return 0
+
+    def uspace_prof_all_end(self, keys, ms, max_records, n):
+        n._obj.value = 0
+        return 0
+
+    def uspace_prof_mfma_peak_clock(self, iters, tf, ghz):
+        tf._obj.value, ghz._obj.value = 1.0, 1.0
+        return 0
+
+    def uspace_prof_hbm_copy(self, nbytes, reps, gb):
+        gb._obj.value = 1.0
+        return 0
+
+
+class _CpuEvent:
+    def record(self):
+        import time
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return 1e3 * (other.t - self.t)
+
+
+class _CpuRuntime:
+    backend = "gloo"
+
+    def __init__(self, local_rank):
+        self.device = torch.device("cpu")
+
+    def init_group(self, rank, world):
+        dist.init_process_group(self.backend, rank=rank, world_size=world)
+
+    def synchronize(self):
+        pass
+
+    def event(self):
+        return _CpuEvent()
+
+    def device_name(self):
+        return "cpu stand-in"
+
+
+def _bench_main_worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    import contextlib
+    import io
+
+    import bench
+    from uspace_amd import _hip
+    fake = _FakeKernels(_hip.lib())
+    _hip.lib = lambda: fake
+    _hip.require_device = lambda t, name="tensor": None
+    _hip.stream_ptr = lambda: None
+    _hip.sync_current_stream = lambda: None
+    bench.RUNTIME = _CpuRuntime
+    bench.MODELS["tiny_u"] = dict(name="uvit", embed_dim=64, depth=2, num_heads=1, num_classes=-1)
+    bench.CONFIGS[2] = dict(model="tiny_u", batch=3, solver="dopri5", ode_steps=4, hook=False)
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main()
+    with open(os.path.join(outdir, f"rank{rank}.txt"), "w") as f:
+        f.write(buf.getvalue())
+    with open(os.path.join(outdir, f"forwards{rank}.txt"), "w") as f:
+        f.write(str(fake.forwards))
+
+
+def test_bench_main_runs_end_to_end_on_two_gloo_ranks(tmp_path):
+    """bench.py's whole main() under the driver's launch form (WORLD_SIZE / RANK / LOCAL_RANK from the environment, 127.0.0.1
+    rendezvous), two CPU processes over gloo, kernels stubbed at _hip.lib() only: the process group forms, every rank solves its
+    own shard (dopri5 on a fixed grid: 1 + 6 n evaluations), the timed solves gather 2 x B rows in rank order, rank 0 prints ONE
+    JSON line whose multi_gpu object names both ranks, their own timings and the gathered row count."""
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_main_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    out0 = open(tmp_path / "rank0.txt").read().strip().splitlines()
+    assert len(out0) == 1 and open(tmp_path / "rank1.txt").read().strip() == ""           # ONE line, from rank 0
+    line = json.loads(out0[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 2 and line["nfe"] == 1 + 6 * 4
+    assert line["config"]["global_batch"] == 6 and line["value"] == pytest.approx(6 * 2 / (line["ms_per_step"] * 2e-3), rel=1e-6)
+    mg = line["multi_gpu"]
+    assert mg["backend"] == "gloo" and mg["rccl_world_size"] == 2 and mg["gathered_rows"] == mg["gathered_rows_expected"] == 6
+    assert [r["rank"] for r in mg["ranks_seen"]] == [0, 1] and [r["local_rank"] for r in mg["ranks_seen"]] == [0, 1]
+    assert len({r["pid"] for r in mg["ranks_seen"]}) == 2 and len(mg["per_rank_median_ms"]) == 2 and len(mg["per_rank_wall_s"]) == 2
+    assert line["ms_per_step"] * 2e-3 == pytest.approx(max(mg["per_rank_wall_s"]), rel=1e-9)             # MAX over ranks
+    # every rank ran its own solves: warm-up + 2 timed + (rank 0: the recorded extra solve) + 2 Euler solves of 4 steps
+    f0, f1 = int(open(tmp_path / "forwards0.txt").read()), int(open(tmp_path / "forwards1.txt").read())
+    assert f1 == 3 * 25 + 2 * 4 and f0 == f1 + 25

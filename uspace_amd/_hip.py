@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libuspace_hip.so")
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_OUT_BF16 = 1, 2, 4, 8, 16
 EPI_CEN_OUT, EPI_LN_IN = 32, 64          # uspace_gemm_bf16_ext only (LayerNorm folded through the GEMMs)
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _ERR = {-1: "USPACE_ERR_ARG", -2: "USPACE_ERR_LAUNCH", -3: "USPACE_ERR_WORKSPACE"}
 
@@ -119,6 +119,7 @@ SIGNATURES = {
     "uspace_prof_gemm_end": (_I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I)]),
     "uspace_prof_all_begin": (_I, [_I]),
     "uspace_prof_all_end": (_I, [ctypes.POINTER(_I), ctypes.POINTER(ctypes.c_double), _I, ctypes.POINTER(_I)]),
+    "uspace_prof_dropped": (_L, []),
     "uspace_prof_mfma_peak": (_I, [_I, ctypes.POINTER(ctypes.c_double)]),
     "uspace_prof_mfma_peak_clock": (_I, [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "uspace_prof_hbm_copy": (_I, [_SZ, _I, ctypes.POINTER(ctypes.c_double)]),
@@ -157,6 +158,11 @@ def check(rc, what):
 
 def stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def sync_current_stream():
+    """Wait for the work enqueued so far on the stream the kernels are launched on."""
+    torch.cuda.current_stream().synchronize()
 
 
 def ptr(t):
@@ -299,6 +305,11 @@ def prof_peaks(mfma_iters=20000, copy_bytes=1 << 30, copy_reps=10):
 
 def prof_all_begin(max_launches=16384):
     check(lib().uspace_prof_all_begin(max_launches), "uspace_prof_all_begin")
+
+
+def prof_dropped():
+    """Launches the recorder could not take (it was full) since the last prof_*_begin()."""
+    return int(lib().uspace_prof_dropped())
 
 
 def prof_all_end(max_records=256):

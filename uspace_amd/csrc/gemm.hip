@@ -1147,6 +1147,7 @@ inline bool tiny_ring(int M, int N, int K) {
     return K / BK >= 16 || (K / BK >= RING_NST && (long)us_cdiv(M, 64) * us_cdiv(N, 64) <= 448);
 }
 inline TileChoice refine_small(TileChoice tc, int M, int N, int K, bool producer) {
+    (void)K;   // the choice of the 64x64 form does not depend on K (K picks its K loop: tiny_ring); kept in the signature for callers that pass it
     if (tc != TILE_SMALL) return tc;
     if ((long)us_cdiv(M, 128) * us_cdiv(N, 128) > 160) return tc;
     if (producer && us_cdiv(N, 64) > 8) return tc;
@@ -1261,30 +1262,39 @@ extern "C" int uspace_gemm_tile_choice(int M, int N, int* split_rows) {
     return c;
 }
 
+// out[8] of uspace_gemm_plan / _plan_k for one tile choice: the shape dispatch_tile launches for it, its row plan and round size
+static void plan_for(TileChoice tc, int M, int N, int K, int m1, int* out) {
+    int BM = 256, BN = 256, per_round = 256;
+    switch (tc) {
+        case TILE_MID: BM = 192; break;
+        case TILE_TALL: BN = 128; break;
+        case TILE_SMALL: BM = BN = 128; per_round = 512; break;
+        case TILE_TINY: BM = BN = 64; per_round = tiny_ring(M, N, K) ? TINY_RING_SLOTS : TINY_SLOTS; break;
+        default: break;
+    }
+    const int rows = tc == TILE_SPLIT ? m1 : M;                 // split: the plan of the 256x256 part
+    const int tn = us_cdiv(N, BN);
+    const Plan p = plan_rows(rows, BM, tn, per_round);
+    out[0] = (int)tc; out[1] = tc == TILE_SPLIT ? m1 : 0; out[2] = BM; out[3] = BN; out[4] = p.tiles_m; out[5] = tn; out[6] = p.n_strip; out[7] = per_round;
+}
+
 extern "C" int uspace_gemm_plan(int M, int N, int* out) {
     if (M <= 0 || N <= 0 || !out) return USPACE_ERR_ARG;
     int m1 = 0;
     const TileChoice tc = choose_tile(M, N, &m1);
-    const int BM = tc == TILE_MID ? 192 : (tc == TILE_SMALL ? 128 : 256), BN = (tc == TILE_SMALL || tc == TILE_TALL) ? 128 : 256;
-    const int per_round = tc == TILE_SMALL ? 512 : 256;
-    const int rows = tc == TILE_SPLIT ? m1 : M;                 // split: the plan of the 256x256 part
-    const int tn = us_cdiv(N, BN);
-    const Plan p = plan_rows(rows, BM, tn, per_round);
-    out[0] = (int)tc; out[1] = m1; out[2] = BM; out[3] = BN; out[4] = p.tiles_m; out[5] = tn; out[6] = p.n_strip; out[7] = per_round;
+    plan_for(tc, M, N, BK, m1, out);
     return USPACE_OK;
 }
 
-// ... for a launch with this K and role (producer of LayerNorm partial sums or not): adds the 64x64 form (out[0] = 5)
+// ... for a launch with this K and role (producer of LayerNorm partial sums or not): exactly the chain dispatch_tile applies --
+// choose_tile, producer_tile for producers (no split form, no 128-wide tiles beyond 8 slots), refine_small (64x64 tiles, out[0] = 5)
 extern "C" int uspace_gemm_plan_k(int M, int N, int K, int producer, int* out) {
-    if (K <= 0) return USPACE_ERR_ARG;
-    US_TRY(uspace_gemm_plan(M, N, out));
-    TileChoice tc = (TileChoice)out[0];
+    if (M <= 0 || N <= 0 || K <= 0 || !out) return USPACE_ERR_ARG;
+    int m1 = 0;
+    TileChoice tc = choose_tile(M, N, &m1);
     if (producer) tc = producer_tile(tc, N);
-    if (refine_small(tc, M, N, K, producer != 0) == TILE_TINY) {
-        const int tn = us_cdiv(N, 64), slots = tiny_ring(M, N, K) ? TINY_RING_SLOTS : TINY_SLOTS;
-        const Plan p = plan_rows(M, 64, tn, slots);
-        out[0] = (int)TILE_TINY; out[1] = 0; out[2] = 64; out[3] = 64; out[4] = p.tiles_m; out[5] = tn; out[6] = p.n_strip; out[7] = slots;
-    }
+    tc = refine_small(tc, M, N, K, producer != 0);
+    plan_for(tc, M, N, K, m1, out);
     return USPACE_OK;
 }
 

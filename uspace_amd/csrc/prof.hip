@@ -22,6 +22,7 @@ struct Recorder {
     std::vector<hipEvent_t> ev;     // start / stop pairs
     std::vector<RecEntry> what;
     size_t used = 0, cap = 0;
+    long dropped = 0;               // launches that matched while the recorder was full (since the last _begin)
 };
 Recorder g_rec;
 
@@ -35,6 +36,7 @@ int rec_arm(int max_launches) {
     g_rec.what.assign((size_t)max_launches, RecEntry{});
     g_rec.cap = (size_t)max_launches;
     g_rec.used = 0;
+    g_rec.dropped = 0;
     return USPACE_OK;
 }
 
@@ -75,8 +77,12 @@ __global__ __launch_bounds__(256) void copy_kernel(const float4* __restrict__ sr
 }  // namespace
 
 int us_rec_begin(int kind, int flags, int M, int N, int K, hipStream_t s) {
-    if (!g_rec.on || g_rec.used >= g_rec.cap) return -1;
+    if (!g_rec.on) return -1;
     if (g_rec.filtered && (kind != US_REC_GEMM || flags != g_rec.f_flags || N != g_rec.f_N || K != g_rec.f_K)) return -1;
+    if (g_rec.used >= g_rec.cap) {       // full: counted, so that a caller can tell a truncated recording from a complete one
+        ++g_rec.dropped;
+        return -1;
+    }
     const int idx = (int)g_rec.used++;
     g_rec.what[idx] = RecEntry{kind, flags, M, N, K};
     (void)hipEventRecord(g_rec.ev[2 * idx], s);
@@ -110,6 +116,8 @@ extern "C" int uspace_prof_gemm_end(double* total_ms, int* n_launches) {
     g_rec.used = 0;
     return USPACE_OK;
 }
+
+extern "C" long uspace_prof_dropped(void) { return g_rec.dropped; }
 
 extern "C" int uspace_prof_all_begin(int max_launches) {
     US_TRY(rec_arm(max_launches));

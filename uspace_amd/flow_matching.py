@@ -8,7 +8,7 @@ the external torchdiffeq.  ``sample_ode`` (the name BASELINE.json uses) aliases 
 import torch
 import torch.nn as nn
 
-from .odeint import Stats, odeint
+from .odeint import FIXED, Stats, odeint
 
 _RTOL = 1e-5
 _ATOL = 1e-5
@@ -58,23 +58,32 @@ class CNFBase(nn.Module):
         raise NotImplementedError
 
     def _timesteps(self, t, x):
-        """(B,) stride-0 fp32 view of the scalar time, like ``t.expand(B)`` (flow_matching.py:33)."""
+        """(B,) stride-0 fp32 view of the scalar time, like ``t.expand(B)`` (flow_matching.py:33).
+
+        READ-ONLY: on a fixed time grid (``_grid_is_fixed``, set by ``_integrate`` from the solver method / ``n_steps``) the
+        device scalar behind the view is cached per (device, t) and handed out again in every later evaluation and solve -- a
+        fixed-step solve visits the same times every time, and the cache saves one fill launch per evaluation.  A consumer
+        that wrote into it (``t *= 1000`` in a ``_velocity`` override or a hook) would change that time for every later use;
+        the reference's own ``t.expand(B)`` view has the same aliasing.  Error-controlled solves choose their own times, no
+        two alike: they get a fresh scalar per call and never touch the cache, which is bounded (oldest entry out first)."""
         if torch.is_tensor(t):
             if t.numel() != 1:
                 return t, None
             th = float(t.item())
         else:
             th = float(t)
-        # a fixed-step solve visits the same times in every solve: keep their device scalars (never written again) instead of one
-        # fill launch per evaluation
+        if not getattr(self, "_grid_is_fixed", False):
+            return torch.full((), th, dtype=torch.float32, device=x.device).expand(x.shape[0]), th
         cache = self.__dict__.setdefault("_t_scalars", {})
         key = (x.device, th)
         ts = cache.get(key)
         if ts is None:
-            if len(cache) >= 1024:
-                cache.clear()
+            while len(cache) >= self._T_SCALARS_MAX:
+                cache.pop(next(iter(cache)))
             ts = cache[key] = torch.full((), th, dtype=torch.float32, device=x.device)
         return ts.expand(x.shape[0]), th
+
+    _T_SCALARS_MAX = 512
 
     def _integrate(self, func, y0, t0, t1, ode_kwargs, n_steps=None):
         stats = self.last_stats if self.last_stats is not None else Stats()
@@ -86,6 +95,8 @@ class CNFBase(nn.Module):
             ops = HipStateOps(y0, group=self.norm_group)
         else:
             ops = None
+        # fixed grid (euler / midpoint / rk4, or an error-controlled method run on n_steps equal steps): the times repeat
+        self._grid_is_fixed = ode_kwargs["method"] in FIXED or n_steps is not None
         out = odeint(func, y0, float(t0), float(t1), method=ode_kwargs["method"], rtol=ode_kwargs["rtol"],
                      atol=ode_kwargs["atol"], step_size=opts.get("step_size"), n_steps=n_steps, stats=stats, ops=ops)
         self.last_stats = stats

@@ -69,7 +69,7 @@ class UViTBase(nn.Module):
         self._cfg = _hip.UvitConfig(img_size, patch_size, in_chans, embed_dim, depth, num_heads, self.hidden,
                                     n_extra, clip_dim, time_first)
         self._packed = None          # (device, versions, blob)
-        self._workspace = {}         # B -> uint8 tensor
+        self._workspace = {}         # (B, device) -> uint8 tensor, at most _MAX_WORKSPACES, least recently used first
         self._delta_cache = {}
         # Replay a captured hipGraph for plain (un-hooked) evaluations.  Off by default since round 3: one C call enqueues a whole
         # evaluation and the kernels take longer to run than to launch at every batch size, so the replay only adds its three small
@@ -197,7 +197,7 @@ class UViTBase(nn.Module):
         arr = (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs])
         _hip.check(L.uspace_uvit_pack_weights(ctypes.byref(cfg), arr, n, _hip.ptr(blob), nbytes, _hip.stream_ptr()),
                    "uspace_uvit_pack_weights")
-        torch.cuda.current_stream().synchronize()   # srcs may be temporaries
+        _hip.sync_current_stream()   # srcs may be temporaries
         self._packed = (device, versions, blob)
         return blob
 
@@ -213,13 +213,20 @@ class UViTBase(nn.Module):
 
     repack = invalidate_packed
 
+    _MAX_WORKSPACES = 2
+
     def _workspace_for(self, B, device):
+        """Workspace of ``uspace_uvit_workspace_bytes(B)`` bytes.  The two most recently used batch sizes stay resident
+        (least recently used goes first): the ``write_scales`` sweep of BASELINE config 5 alternates one B x n_scales solve
+        with plain B solves (tools/utils_vis.py:189-198), and one slot would reallocate hundreds of MB at every switch."""
         key = (B, str(device))
-        ws = self._workspace.get(key)
+        ws = self._workspace.pop(key, None)
         if ws is None:
             nbytes = _hip.lib().uspace_uvit_workspace_bytes(ctypes.byref(self._cfg), B)
+            while len(self._workspace) >= self._MAX_WORKSPACES:
+                self._workspace.pop(next(iter(self._workspace)))          # dicts keep insertion order: the oldest use
             ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-            self._workspace = {key: ws}     # keep one batch size resident
+        self._workspace[key] = ws            # most recently used last
         return ws
 
     # ------------------------------------------------------------------ hipGraph replay (plain evaluations)

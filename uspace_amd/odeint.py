@@ -101,7 +101,6 @@ class HipStateOps:
         self._result = torch.zeros(2, dtype=torch.float32, device=like.device)      # [rms, sum of squares]
         self.group = group
         self._pair = torch.zeros(2, dtype=torch.float64, device=like.device) if group is not None else None
-        self._pair_n = None
 
     def prepare(self, y):
         return y.detach().to(self._torch.float32).contiguous()
@@ -120,16 +119,14 @@ class HipStateOps:
             self._hip.ode_error_norm(y0, y1, ks, coefs, rtol, atol, self._scratch, self._result)
         if self.group is None:
             return float(self._result[0].item()) if n > 0 else 0.0
-        # (sum of squares, count) of this rank -> global RMS; the count is written to the device only when it changes
+        # (sum of squares, count) of this rank -> global RMS.  Both slots are rewritten before every all-reduce: it leaves
+        # the GLOBAL sum and count in them.
         if n > 0:
             self._pair[0].copy_(self._result[1])
         else:
             self._pair[0].zero_()
-        if self._pair_n != n:
-            self._pair[1].fill_(float(n))
-            self._pair_n = n
-        ms = allreduce_mean_square(self._pair, self.group)     # (the all-reduce overwrites pair[1] with the global count)
-        self._pair_n = None
+        self._pair[1].fill_(float(n))
+        ms = allreduce_mean_square(self._pair, self.group)
         return math.sqrt(ms)
 
 
