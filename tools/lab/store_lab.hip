@@ -21,9 +21,11 @@
     } while (0)
 
 template <int P>
-__global__ __launch_bounds__(512) void store_kernel(unsigned short* out, int ld, int tiles_n, unsigned seed) {
+__global__ __launch_bounds__(512) void store_kernel(unsigned short* out, int ld, int tiles_n, unsigned seed, int tm_mod) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    // tm_mod > 0 (round 4): every workgroup writes into the first tm_mod tile rows -- an L2-resident window, so that the time is the
+    // CUs' store ISSUE rate with nothing draining to HBM
+    const int tm = tm_mod > 0 ? (int)(blockIdx.x / tiles_n) % tm_mod : (int)(blockIdx.x / tiles_n), tn = blockIdx.x % tiles_n;
     char* base = (char*)(out + (size_t)tm * 256 * ld + tn * 256);
     const size_t rb = (size_t)ld * 2;           // row stride in bytes
     // each wave owns 32 rows x 512 B of the tile (16 KiB)
@@ -62,15 +64,15 @@ __global__ __launch_bounds__(512) void store_kernel(unsigned short* out, int ld,
 }
 
 template <int P>
-static float run(unsigned short* d, int M, int ld, int reps) {
+static float run(unsigned short* d, int M, int ld, int reps, int tm_mod = 0) {
     const int tiles_n = ld / 256, tiles_m = M / 256;
     hipEvent_t a, b;
     HCHECK(hipEventCreate(&a));
     HCHECK(hipEventCreate(&b));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(store_kernel<P>, dim3(tiles_m * tiles_n), dim3(512), 0, 0, d, ld, tiles_n, i);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(store_kernel<P>, dim3(tiles_m * tiles_n), dim3(512), 0, 0, d, ld, tiles_n, i, tm_mod);
     HCHECK(hipDeviceSynchronize());
     HCHECK(hipEventRecord(a, 0));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(store_kernel<P>, dim3(tiles_m * tiles_n), dim3(512), 0, 0, d, ld, tiles_n, i);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(store_kernel<P>, dim3(tiles_m * tiles_n), dim3(512), 0, 0, d, ld, tiles_n, i, tm_mod);
     HCHECK(hipEventRecord(b, 0));
     HCHECK(hipEventSynchronize(b));
     float ms;
@@ -87,7 +89,10 @@ int main() {
         const float t[5] = {run<0>(d, M, ld, 20), run<1>(d, M, ld, 20), run<2>(d, M, ld, 20), run<3>(d, M, ld, 20), run<4>(d, M, ld, 20)};
         const char* names[5] = {"16r x 32B (x2)", "16r x 64B (x4)", "8r x 128B", "4r x 256B", "2r x 512B"};
         printf("[%d x %d] bf16 = %.0f MB, %d tiles of 256x256 (%.1f per CU)\n", M, ld, mb, (M / 256) * (ld / 256), (M / 256) * (ld / 256) / 256.0);
-        for (int p = 0; p < 5; ++p) printf("  %-16s %7.1f us  %6.2f TB/s\n", names[p], t[p], mb / t[p] * 1e-6 * 1e6 / 1e6);
+        for (int p = 0; p < 5; ++p) printf("  %-16s %7.1f us  %6.2f TB/s\n", names[p], t[p], mb / t[p]);
+        // the same launches into a window of one tile row (256 x ld bf16: 0.5 - 1.5 MB, L2-resident)
+        const float w[5] = {run<0>(d, M, ld, 20, 1), run<1>(d, M, ld, 20, 1), run<2>(d, M, ld, 20, 1), run<3>(d, M, ld, 20, 1), run<4>(d, M, ld, 20, 1)};
+        for (int p = 0; p < 5; ++p) printf("  %-16s %7.1f us  %6.2f TB/s   (all workgroups into one tile row: issue rate, no HBM drain)\n", names[p], w[p], mb / w[p]);
         HCHECK(hipFree(d));
     }
     return 0;

@@ -67,7 +67,8 @@ constexpr int BK = 64;           // bf16 elements per K step (128 B per LDS row)
 #endif
 #if !USPACE_LAB
 #if defined(USPACE_ABLATE_NOSTORE) || defined(USPACE_ABLATE_NOEPI) || defined(USPACE_ABLATE_NOGELU) || defined(USPACE_DMA_FLAT) || \
-    defined(USPACE_RING_PREFETCH_ALL) || defined(USPACE_TINY_UNROLL) || defined(USPACE_EARLY_BARRIER) || defined(USPACE_TALL_COST)
+    defined(USPACE_RING_PREFETCH_ALL) || defined(USPACE_TINY_UNROLL) || defined(USPACE_EARLY_BARRIER) || defined(USPACE_TALL_COST) || defined(USPACE_CHAIN) || \
+    defined(USPACE_CHAIN_ABL) || defined(USPACE_CHAIN_DMA8) || defined(USPACE_CHAIN_SPLIT)
 #error "measurement switches need -DUSPACE_LAB=1 (tools/lab/build_variant.sh); the product build takes none"
 #endif
 #define USPACE_ABLATE_NOSTORE 0
@@ -95,6 +96,9 @@ constexpr int BK = 64;           // bf16 elements per K step (128 B per LDS row)
 #endif
 #ifndef USPACE_TINY_UNROLL
 #define USPACE_TINY_UNROLL 1
+#endif
+#ifndef USPACE_CHAIN
+#define USPACE_CHAIN 0           // 1: multi-round store-only launches of 256x256 tiles take the chain form (gemm_chain.h)
 #endif
 constexpr int ROW_BYTES = 128;
 
@@ -970,6 +974,10 @@ int launch(const GemmArgs& a, hipStream_t s, int wg_per_round) {
     return USPACE_OK;
 }
 
+#if USPACE_CHAIN
+#include "../../tools/lab/gemm_chain.h"   // lab only (round 4, measured and not landed: profiles/r04_gemm_chain.md)
+#endif
+
 // ---- small launches: 128x128 tiles that fill a fraction of the CUs, with a long K (fc2 / skip_linear of a small batch:
 // 36 tiles x 32 K tiles for U-ViT-S at 4 x 257 rows).  A lone 128x128 workgroup spends 0.39 us per K tile (its CU's LDS-DMA
 // issue rate, `profiles/r02_gemm_ablation.md` section 7), so the K range is cut into S parts on S times the CUs
@@ -1183,6 +1191,15 @@ int dispatch_tile(const GemmArgs& a, hipStream_t s) {
             }
         }
     }
+#if USPACE_CHAIN
+    if constexpr ((FLAGS & (USPACE_EPI_RESIDUAL | USPACE_EPI_OUT_F32 | USPACE_EPI_CEN_OUT)) == 0) {
+        if (tc == TILE_BIG) {
+            const int tn = us_cdiv(a.N, 256);
+            const Plan p = plan_rows(a.M, 256, tn, 256);
+            if (chain_ok(a, p, tn, FLAGS)) return launch_chain<FLAGS>(a, p, tn, s);
+        }
+    }
+#endif
     switch (tc) {
         case TILE_BIG: return launch<256, 256, 2, 4, FLAGS>(a, s, 256);
         case TILE_MID: return launch<192, 256, 2, 4, FLAGS>(a, s, 256);
