@@ -24,6 +24,10 @@ What is pinned:
   big_{S,L}_{u,t}                   seed-regenerated weights (sha256 pinned) -> out, B=2
   euler20_S_u                       BASELINE config 1: 20 fixed Euler steps, B=4, driven by
                                     a plain loop written here around the reference nnet
+  hooked_traj                       whole HOOKED solves through the reference networks with the reference's own hooks active: tiny
+                                    uncond write_attr (tail / head) over 100 Euler steps, tiny T2I p2p_rescale encode -> decode, and the
+                                    50-step Euler end state of BASELINE configs[2] (U-ViT-L T2I, B = 2); which steps edited is recorded
+                                    from the reference's own file reads / hook calls
   traj_L_u                          BASELINE config 2 (the headline shape) end to end at B=2: 50 fixed Euler steps and
                                     50 fixed Dormand-Prince steps (FSAL, 301 evaluations) of the reference U-ViT-L,
                                     both driven by loops written here (flow_matching.py:130-151 selects the solver;
@@ -428,6 +432,124 @@ def make_traj_L_u(uvit, timing):
     save("traj_L_u.npz", z=z.numpy(), x1_euler50=x1_euler.numpy(), x1_dopri5_50=y.numpy(), n_steps=np.int32(n), nfe_dopri5=np.int32(nfe))
 
 
+# --------------------------------------------------------------------------- hooked trajectories (round 4)
+def _fixed_grid(t0, t1, h):
+    """torchdiffeq FixedGridODESolver._grid_constructor_from_step_size on fp32 tensors (published algorithm; the package is absent):
+    niters = ceil((t1 - t0) / h + 1); grid = arange(niters) * h + t0; grid[-1] = t1.  Decreasing spans are integrated by the caller in
+    reversed time (torchdiffeq's _flip: the solver sees t' = -t and f'(t', y) = -f(-t', y))."""
+    t0, t1, h = torch.tensor(t0, dtype=torch.float32), torch.tensor(t1, dtype=torch.float32), torch.tensor(h, dtype=torch.float32)
+    niters = torch.ceil((t1 - t0) / h + 1).item()
+    grid = torch.arange(0, niters, dtype=torch.float32) * h + t0
+    grid[-1] = t1
+    return grid
+
+
+def _euler(f, y, t0, t1, h):
+    """y(t1) by fixed-grid Euler steps as torchdiffeq takes them: dt = t_{k+1} - t_k in fp32, y += dt * f(t_k, y)."""
+    if t1 < t0:                                    # reversed time
+        grid = _fixed_grid(-t0, -t1, h)
+        for a, b in zip(grid[:-1], grid[1:]):
+            y = y + (b - a) * (-f(-a, y))
+        return y, len(grid) - 1
+    grid = _fixed_grid(t0, t1, h)
+    for a, b in zip(grid[:-1], grid[1:]):
+        y = y + (b - a) * f(a, y)
+    return y, len(grid) - 1
+
+
+def hooked_delta_table(k, shape=(5, 4, 16, 16)):
+    """The direction table of step file delta_{k/100:.2f}.npy: a different table for every time, so that a wrong file shows."""
+    return (np.random.default_rng(4000 + k).standard_normal(shape) * 0.3).astype(np.float32)
+
+
+def make_hooked_traj(uvit, uvit_t2i, m_u, x_u, m_t, x_t, ctx_t, timing, skip_large=False):
+    """Whole hooked solves driven through the REFERENCE networks with the reference's own hooks active (VERDICT r3 task 4):
+    (a) tiny uncond, libs/dissection.py:115-186 write_attr at edit_loc tail / head, Euler step 0.01 over [0, 1], t_edit 0.4 --
+        which steps edit on the fp32 grid (0.29999998 -> "0.30", "0.00" never) is recorded from the reference's own file reads;
+    (b) tiny T2I, tools/utils_t2i.py:265-296 p2p_rescale on block 1: encode 1 -> 0 (fm_direction "encode": never edits), then decode
+        0 -> 1 of the encoded latent (fm_direction "decode": edits while "{t:.2f}" <= t_edit, t = 0.00 included), Euler step 0.05,
+        flow_matching_t2i.py:105-146;
+    (c) BASELINE configs[2]: U-ViT-L T2I, 50 Euler steps, B = 2, end state."""
+    import importlib
+    dis = importlib.import_module("libs.dissection")
+    ut2i = importlib.import_module("tools.utils_t2i")
+    out = {}
+    # ---- (a)
+    with tempfile.TemporaryDirectory() as d:
+        for k in range(0, 101):
+            np.save(os.path.join(d, f"delta_{k / 100:.2f}.npy"), hooked_delta_table(k))
+        reads = []
+        orig = dis._read_npz_bcwh
+
+        def counting(npz_path, ith_ele, device):
+            reads.append(os.path.basename(npz_path))
+            return orig(npz_path=npz_path, ith_ele=ith_ele, device=device)
+
+        dis._read_npz_bcwh = counting
+        try:
+            for tag, kw in (("tail", dict(edit_loc="tail", ith_attr=2, write_scale=1.0)),
+                            ("head", dict(edit_loc="head", ith_attr="1_3", write_scale=-4.0))):
+                reads.clear()
+                kwargs = dict(dissect_task="uspace_uvit", dissect_name="write_attr", t_edit=0.4, write_path_root=d, **kw)
+                B = x_u.shape[0]
+                with torch.no_grad():
+                    f = lambda t, y: m_u(y, t.expand(B), None, **kwargs)[0]          # flow_matching.py:30-34
+                    y1, n = _euler(f, x_u.clone(), 0.0, 1.0, 0.01)
+                    g = lambda t, y: m_u(y, t.expand(B), None, edit_loc=None)[0]
+                    y_plain, _ = _euler(g, x_u.clone(), 0.0, 1.0, 0.01)
+                assert n == 100
+                out[f"u_{tag}_x1"] = y1.numpy()
+                out[f"u_{tag}_files"] = np.frombuffer(json.dumps(list(reads)).encode(), dtype=np.uint8)
+                assert reads == [f"delta_{k / 100:.2f}.npy" for k in range(1, 41)], reads[:5]
+            out["u_plain_x1"] = y_plain.numpy()
+        finally:
+            dis._read_npz_bcwh = orig
+    # ---- (b)
+    ids = [np.array([3, 5], dtype=np.int64), np.array([], dtype=np.int64), np.array([0, 76, 76], dtype=np.int64)]
+    calls = []
+    orig_p2p = ut2i._p2p_rescale
+
+    def counting_p2p(attention_map, target_context_ids, p2p_multiplier=0):
+        calls.append(1)
+        return orig_p2p(attention_map, target_context_ids=target_context_ids, p2p_multiplier=p2p_multiplier)
+
+    ut2i._p2p_rescale = counting_p2p
+    try:
+        B = x_t.shape[0]
+        base = dict(dissect_name="p2p", t_edit=0.5, block_id=[1], token_kwargs=dict(token_dissect="p2p_rescale", p2p_multiplier=40.0))
+        with torch.no_grad():
+            def field(direction):
+                return lambda t, y: m_t(y, t.expand(B), context=ctx_t, fm_direction=direction,
+                                        target_context_ids=[a.copy() for a in ids], **base)[0]
+            z_enc, n_enc = _euler(field("encode"), x_t.clone(), 1.0, 0.0, 0.05)
+            n_calls_enc = len(calls)
+            x_dec, n_dec = _euler(field("decode"), z_enc.clone(), 0.0, 1.0, 0.05)
+            n_calls_dec = len(calls) - n_calls_enc
+            plain = lambda t, y: m_t(y, t.expand(B), context=ctx_t)[0]
+            x_dec_plain, _ = _euler(plain, z_enc.clone(), 0.0, 1.0, 0.05)
+        assert (n_enc, n_dec, n_calls_enc, n_calls_dec) == (20, 20, 0, 11), (n_enc, n_dec, n_calls_enc, n_calls_dec)
+        out.update(t_z_enc=z_enc.numpy(), t_x_dec=x_dec.numpy(), t_x_dec_plain=x_dec_plain.numpy(),
+                   t_edit_calls=np.array([n_calls_enc, n_calls_dec], np.int32))
+    finally:
+        ut2i._p2p_rescale = orig_p2p
+    # ---- (c)
+    if not skip_large:
+        m = build_big(uvit, uvit_t2i, "L", "t")
+        g = torch.Generator().manual_seed(INPUT_SEED)
+        B = 2
+        z = torch.randn(B, 4, 32, 32, generator=g)
+        ctx = torch.randn(B, 77, 768, generator=g)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            x1, n = _euler(lambda t, y: m(y, t.expand(B), context=ctx)[0], z.clone(), 0.0, 1.0, 0.02)
+        assert n == 50
+        timing["traj_L_t_B2_euler50_total_s"] = time.perf_counter() - t0
+        out.update(Lt_z=z.numpy(), Lt_ctx=ctx.numpy(), Lt_x1_euler50=x1.numpy(), Lt_sha256=np.frombuffer(sd_sha256(m).encode(), dtype=np.uint8))
+        del m
+    save("hooked_traj.npz", **out)
+
+
+
 def make_attr_directions():
     """tools/utils_attr.py:124-145 cal_delta_direction on synthetic features: mean(pos) - mean(neg) per
     attribute (the direction files the write hook consumes)."""
@@ -609,7 +731,27 @@ def main():
     ap.add_argument("--only-traj", action="store_true", help="regenerate only traj_L_u.npz")
     ap.add_argument("--only-clip", action="store_true", help="regenerate only clip_text_tiny.npz (no reference import needed)")
     ap.add_argument("--only-word-inds", action="store_true", help="regenerate only word_inds.json")
+    ap.add_argument("--only-hooked", action="store_true", help="regenerate only hooked_traj.npz")
     args = ap.parse_args()
+    if args.only_hooked:
+        uvit, uvit_t2i = _refshim.load_reference()
+        torch.set_grad_enabled(False)
+        # the tiny networks and inputs of tiny_u.npz / tiny_t2i.npz (same seeds, same construction order)
+        torch.manual_seed(WEIGHT_SEED)
+        m_u = uvit.UViT(num_classes=-1, **TINY).eval()
+        x_u = torch.randn(3, 4, 16, 16, generator=torch.Generator().manual_seed(INPUT_SEED))
+        torch.manual_seed(WEIGHT_SEED + 2)
+        m_t = uvit_t2i.UViT(clip_dim=64, num_clip_token=77, **TINY).eval()
+        g = torch.Generator().manual_seed(INPUT_SEED)
+        x_t = torch.randn(3, 4, 16, 16, generator=g)
+        ctx_t = torch.randn(3, 77, 64, generator=g)
+        timing = {}
+        make_hooked_traj(uvit, uvit_t2i, m_u, x_u, m_t, x_t, ctx_t, timing, skip_large=args.skip_large)
+        tpath = os.path.join(HERE, "ref_cpu_timing.json")
+        old = json.load(open(tpath))
+        old.update(timing)
+        json.dump(old, open(tpath, "w"), indent=1)
+        return
     if args.only_word_inds:
         make_word_inds()
         return
@@ -644,6 +786,8 @@ def main():
     make_pca_components()
     make_clip_text()
     make_word_inds()
+    hooked_timing = {}
+    make_hooked_traj(uvit, uvit_t2i, m, x, mt, xt, ctx, hooked_timing, skip_large=args.skip_large)
     if not args.skip_large:
         timing = dict(threads=torch.get_num_threads(), nproc=os.cpu_count(),
                       cpu=[l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0],
@@ -651,6 +795,7 @@ def main():
         make_big(uvit, uvit_t2i, timing)
         make_euler20(uvit, timing)
         make_traj_L_u(uvit, timing)
+        timing.update(hooked_timing)
         with open(os.path.join(HERE, "ref_cpu_timing.json"), "w") as f:
             json.dump(timing, f, indent=1)
         print(json.dumps(timing, indent=1))

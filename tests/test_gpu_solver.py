@@ -341,3 +341,88 @@ def test_pca_small_variance_components_survive_the_gram_matrix():
         # orthonormal set
         gmat = got.reshape(len(sv), -1).astype(np.float64)
         assert np.abs(gmat @ gmat.T - np.eye(len(sv))).max() < 1e-3
+
+
+# --------------------------------------------------------------------------- hooked solves against the REFERENCE's own trajectories
+def test_cnf_hooked_uncond_solves_match_reference_trajectories(golden_dir, tmp_path, monkeypatch):
+    """hooked_traj.npz (a): the reference network + the reference's dissect_helper_uvit over 100 Euler steps (make_golden.py::
+    make_hooked_traj).  The same solve through CNF.decode: end state within the trajectory tolerance, and the product edits in exactly
+    the evaluations the reference did -- 40 of 100: grid points k * 0.01 (fp32) with "0.01" <= "{t:.2f}" <= "0.40", never "0.00"."""
+    from tests.test_oracle_golden import HOOKED_U, write_hooked_tables
+    from uspace_amd import _hip
+    from uspace_amd.flow_matching import CNF
+    from uspace_amd.libs import dissection
+    from uspace_amd.tools.utils_uvit import get_nnet
+    z = np.load(os.path.join(golden_dir, "hooked_traj.npz"))
+    zt, sd = load_sd(golden_dir, "tiny_u.npz")
+    net = get_nnet("uvit", num_classes=-1, **TINY)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.cuda().eval()
+    cnf = CNF(net)
+    write_hooked_tables(str(tmp_path))
+    planned, adds = [], []
+    real_plan, real_add = dissection.plan_uspace_hook, _hip.add_broadcast
+    monkeypatch.setattr(dissection, "plan_uspace_hook", lambda digit, kw: (lambda p: (planned.append((digit, None if p is None else os.path.basename(p.path))), p)[1])(real_plan(digit, kw)))
+    monkeypatch.setattr(_hip, "add_broadcast", lambda *a, **k: (adds.append(1), real_add(*a, **k))[1])
+    x0 = torch.from_numpy(zt["x"]).cuda()
+    import json
+    for tag, kw in HOOKED_U:
+        planned.clear(), adds.clear()
+        x1 = cnf.decode(x0, None, dissect_task="uspace_uvit", dissect_name="write_attr", t_edit=0.4, write_path_root=str(tmp_path),
+                        solver_kwargs=_solver_kwargs(solver_fix_step=0.01), **kw)
+        assert cnf.last_stats.nfe == 100 and len(planned) == 100
+        fired = [f for _d, f in planned if f is not None]
+        assert fired == json.loads(bytes(z[f"u_{tag}_files"]).decode()) and len(adds) == 40
+        assert [d for d, f in planned if f is None][:1] == ["0.00"] and planned[30] == ("0.30", "delta_0.30.npy") and planned[41][1] is None
+        r = rel_l2(x1.cpu().numpy(), z[f"u_{tag}_x1"])
+        assert r < 5e-3, (tag, r)
+        shift = rel_l2(z["u_plain_x1"], z[f"u_{tag}_x1"])
+        assert r < 0.25 * shift, (tag, r, shift)          # far closer to the hooked reference than the unhooked solve is
+
+
+def test_cnf_t2i_encode_then_decode_matches_reference_trajectories(golden_dir, monkeypatch):
+    """hooked_traj.npz (b): reference U-ViT T2I + editing_attention_map_vit (p2p_rescale on block 1, multiplier 40): encode 1 -> 0
+    never edits (fm_direction "encode"), decode 0 -> 1 of the encoded latent edits in 11 of its 20 evaluations ("0.00" ... "0.50")."""
+    from tests.test_oracle_golden import HOOKED_T, HOOKED_T_IDS
+    from uspace_amd.flow_matching_t2i import CNF
+    from uspace_amd.tools import utils_t2i
+    from uspace_amd.tools.utils_uvit import get_nnet
+    z = np.load(os.path.join(golden_dir, "hooked_traj.npz"))
+    zt, sd = load_sd(golden_dir, "tiny_t2i.npz")
+    net = get_nnet("uvit_t2i", clip_dim=64, num_clip_token=77, **TINY)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.cuda().eval()
+    cnf = CNF(net)
+    tables = []
+    real = utils_t2i.key_scale_table
+    monkeypatch.setattr(utils_t2i, "key_scale_table", lambda *a, **k: (lambda t: (tables.append(None if t is None else [int(b) for b in range(t.shape[0]) if (t[b] != 1).any()]), t)[1])(real(*a, **k)))
+    x0, ctx = torch.from_numpy(zt["x"]).cuda(), torch.from_numpy(zt["ctx"]).cuda()
+    kw = dict(HOOKED_T, target_context_ids=HOOKED_T_IDS, solver_kwargs=_solver_kwargs(solver_fix_step=0.05))
+    z_enc = cnf.encode(x0, ctx, **dict(kw))
+    assert cnf.last_stats.nfe == 20 and tables == [None] * 20
+    tables.clear()
+    x_dec = cnf.decode(torch.from_numpy(z["t_z_enc"]).cuda(), ctx, **dict(kw))
+    assert cnf.last_stats.nfe == 20
+    assert [t is not None for t in tables] == [True] * 11 + [False] * 9 and all(t == [1] for t in tables[:11])      # block 1 only
+    assert [0, 11] == z["t_edit_calls"].tolist()
+    assert rel_l2(z_enc.cpu().numpy(), z["t_z_enc"]) < 5e-3
+    r = rel_l2(x_dec.cpu().numpy(), z["t_x_dec"])
+    assert r < 5e-3, r
+
+
+def test_cnf_euler50_L_t_matches_reference_trajectory(golden_dir):
+    """BASELINE configs[2] end to end at B = 2: U-ViT-L T2I (weights rebuilt from the seed), 50 Euler steps."""
+    from uspace_amd.flow_matching_t2i import CNF
+    from uspace_amd.tools.utils_uvit import get_nnet
+    z = np.load(os.path.join(golden_dir, "hooked_traj.npz"))
+    torch.manual_seed(1234)
+    net = get_nnet("uvit_t2i", img_size=32, patch_size=2, in_chans=4, embed_dim=1024, depth=20, num_heads=16, mlp_ratio=4, qkv_bias=False,
+                   mlp_time_embed=False, clip_dim=768, num_clip_token=77)
+    # (the seeded init reproduces the reference's weights bit for bit on the host that generated the fixture --
+    # tests/test_host_logic.py pins that by sha256 --; another CPU's erfinv may differ in the last bit, so no hash here)
+    cnf = CNF(net.cuda().eval())
+    x1 = cnf.decode(torch.from_numpy(z["Lt_z"]).cuda(), torch.from_numpy(z["Lt_ctx"]).cuda(), dissect_name="none",
+                    solver_kwargs=_solver_kwargs(solver_fix_step=0.02))
+    assert cnf.last_stats.nfe == 50
+    r = rel_l2(x1.cpu().numpy(), z["Lt_x1_euler50"])
+    assert r < 5e-3, r

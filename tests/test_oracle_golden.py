@@ -180,3 +180,61 @@ def test_pca_oracle_matches_reference(golden_dir):
     for g, r in zip(got.reshape(len(got), -1), ref.reshape(len(ref), -1)):
         s = np.sign(np.dot(g, r))
         np.testing.assert_allclose(g * s, r, atol=2e-5)
+
+
+def hooked_delta_table(k, shape=(5, 4, 16, 16)):
+    """tests/golden/make_golden.py::hooked_delta_table: the table of delta_{k/100:.2f}.npy (a different one for every time)."""
+    return (np.random.default_rng(4000 + k).standard_normal(shape) * 0.3).astype(np.float32)
+
+
+def write_hooked_tables(d):
+    for k in range(0, 101):
+        np.save(os.path.join(d, f"delta_{k / 100:.2f}.npy"), hooked_delta_table(k))
+
+
+HOOKED_U = (("tail", dict(edit_loc="tail", ith_attr=2, write_scale=1.0)), ("head", dict(edit_loc="head", ith_attr="1_3", write_scale=-4.0)))
+HOOKED_T = dict(dissect_name="p2p", t_edit=0.5, block_id=[1], token_kwargs=dict(token_dissect="p2p_rescale", p2p_multiplier=40.0))
+HOOKED_T_IDS = [np.array([3, 5], dtype=np.int64), np.array([], dtype=np.int64), np.array([0, 76, 76], dtype=np.int64)]
+
+
+def test_hooked_trajectories_follow_the_reference(golden_dir, monkeypatch):
+    """Hook x solver interplay pinned by the REFERENCE (VERDICT r3 task 4): hooked_traj.npz holds whole solves driven through the
+    reference networks with the reference's own hooks active (generator: make_golden.py::make_hooked_traj).  The oracle's
+    integrator + forward + hooks must land on the same end states AND edit in the same evaluations: 40 of 100 Euler steps on the
+    fp32 grid k * 0.01 (files delta_0.01 ... delta_0.40: "0.00" never edits, 0.29999998 reads delta_0.30), and for the attention-map
+    hook none of the 20 encode evaluations and 11 of the 20 decode evaluations (t = 0.00 ... 0.50; no "0.00" rule there)."""
+    from oracle import odeint_oracle as OO
+    z = np.load(os.path.join(golden_dir, "hooked_traj.npz"))
+    zt, sd = _load(golden_dir, "tiny_u.npz")
+    spec = O.UViTSpec(**TINY)
+    tol = dict(rtol=2e-4, atol=2e-4)               # 100 steps of fp32 round-off on O(1) states
+    with tempfile.TemporaryDirectory() as d:
+        write_hooked_tables(d)
+        files = []
+        real_load = np.load
+        monkeypatch.setattr(O.np, "load", lambda p, *a, **k: (files.append(os.path.basename(str(p))), real_load(p, *a, **k))[1])
+        for tag, kw in HOOKED_U:
+            files.clear()
+            kwargs = dict(dissect_task="uspace_uvit", dissect_name="write_attr", t_edit=0.4, write_path_root=d, **kw)
+            cnt = {}
+            x1 = OO.solve(lambda t, y: O.uvit_forward(spec, sd, y, t, **kwargs), zt["x"], 0.0, 1.0, method="euler", step_size=0.01, counters=cnt)
+            assert cnt["nfe"] == 100
+            assert files == json.loads(bytes(z[f"u_{tag}_files"]).decode()) == [f"delta_{k / 100:.2f}.npy" for k in range(1, 41)]
+            np.testing.assert_allclose(x1, z[f"u_{tag}_x1"], **tol)
+            assert np.abs(z[f"u_{tag}_x1"] - z["u_plain_x1"]).max() > 0.02          # the edits moved the end state by 100x the tolerance
+        monkeypatch.undo()
+    zt2, sd2 = _load(golden_dir, "tiny_t2i.npz")
+    spec2 = O.UViTSpec(t2i=True, clip_dim=64, num_clip_token=77, **TINY)
+    fired = []
+    real = O.p2p_column_scale
+    monkeypatch.setattr(O, "p2p_column_scale", lambda B, L, t, kw, blk: (lambda r: (fired.append(blk) if r is not None else None, r)[1])(real(B, L, t, kw, blk)))
+
+    def field(direction):
+        return lambda t, y: O.uvit_forward(spec2, sd2, y, t, context=zt2["ctx"], fm_direction=direction, target_context_ids=HOOKED_T_IDS, **HOOKED_T)
+    z_enc = OO.solve(field("encode"), zt2["x"], 1.0, 0.0, method="euler", step_size=0.05)
+    n_enc = len(fired)
+    x_dec = OO.solve(field("decode"), z["t_z_enc"], 0.0, 1.0, method="euler", step_size=0.05)
+    assert [n_enc, len(fired) - n_enc] == z["t_edit_calls"].tolist() == [0, 11] and set(fired) == {1}
+    np.testing.assert_allclose(z_enc, z["t_z_enc"], **tol)
+    np.testing.assert_allclose(x_dec, z["t_x_dec"], **tol)
+    assert np.abs(z["t_x_dec"] - z["t_x_dec_plain"]).max() > 2e-3
