@@ -172,6 +172,23 @@ def test_attention(hip, B, L, H, scaled):
     np.testing.assert_allclose(got, ref, rtol=2e-2, atol=2e-2 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("B,L,H", [(64, 257, 16), (33, 257, 16), (41, 257, 16), (64, 334, 16), (40, 334, 8), (65, 334, 4), (23, 300, 16)])
+def test_attention_several_heads_per_workgroup_is_bit_equal_to_one(hip, B, L, H):
+    """More heads than resident workgroups (two per CU at L <= 272, one above): a workgroup walks 2 - 4 heads and fetches the next
+    head's K / V through registers while it computes (attention.hip, HPW).  Same arithmetic: every head's output is bit-equal to the
+    one-head-per-workgroup launch that small batches take, checked by running the batch in pieces of at most 256 heads; against the
+    oracle on a sample of heads."""
+    rng = np.random.default_rng(B * 7 + L + H)
+    qkv = torch.from_numpy(bf16_round(_rand(rng, B * L, 3 * H * 64, scale=1.5))).to("cuda", dtype=torch.bfloat16)
+    whole = hip.attention(qkv, B, L, H)
+    nb = max(1, 256 // H)
+    parts = [hip.attention(qkv[b0 * L:min(B, b0 + nb) * L].contiguous(), min(B, b0 + nb) - b0, L, H) for b0 in range(0, B, nb)]
+    assert torch.equal(whole, torch.cat(parts))
+    for b in (0, B // 2, B - 1):
+        ref = C.attention(qkv[b * L:(b + 1) * L].float().cpu().numpy().reshape(1, L, -1), H)
+        assert rel_l2(whole[b * L:(b + 1) * L].float().cpu().numpy().reshape(1, L, H * 64), ref) < 6e-3
+
+
 def test_attention_spiked_row_softmax_is_stable(hip):
     # one key dominates one query by a large margin: exp underflow elsewhere must not produce NaN
     rng = np.random.default_rng(3)

@@ -48,10 +48,17 @@ __device__ __forceinline__ uint2 lds_read_tr16(const char* p) {
 // CAUSAL: key k is visible to query q iff k <= q (CLIP text transformer); the key_scale edit does not apply there.
 // QS: workgroups per (batch, head): small batches (B * H of a few dozen on 256 CUs) cut the query tiles of a head over QS
 // workgroups, each staging K and V for itself -- the kernel is latency-bound there, not traffic-bound.
-template <int NT, int LC, bool SCALED, int NW, bool CAUSAL = false, int QS = 1>
+// HPW: heads per workgroup.  With more heads than resident workgroups (B * H = 1024 at batch 64: two rounds of 512 workgroups for
+// L = 257, four rounds of 256 for L = 334) every round began with all of its workgroups staging K and V at once -- HBM-bound and
+// with nothing to compute: 5.5 us per round, `profiles/r02_gemm_ablation.md` section 4.  A workgroup that owns HPW heads
+// (blockIdx.x, blockIdx.x + gridDim.x, ...) requests the NEXT head's K and V rows with plain global loads into registers while it
+// computes the current one (70 KB over 256 lanes = 18 x 16 B per lane; a handful per query tile, so that no wait of the tile loop
+// has more than a chunk behind it) and writes them to LDS between two barriers when the head is done: the same lane-linear image the
+// LDS-DMA of the first head produces, bit-equal results.
+template <int NT, int LC, bool SCALED, int NW, bool CAUSAL = false, int QS = 1, int HPW = 1>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void attention_kernel(const bf16_t* __restrict__ qkv,
                                                            const float* __restrict__ key_scale,
-                                                           bf16_t* __restrict__ out, int L_rt, int H) {
+                                                           bf16_t* __restrict__ out, int L_rt, int H, int BH) {
     const int L = LC > 0 ? LC : L_rt;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NP = (NT + 1) / 2;       // 32-key steps of the P.V product
@@ -64,16 +71,23 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void attention_kernel(con
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bh = QS > 1 ? blockIdx.x / QS : blockIdx.x;
+    static_assert(HPW == 1 || (QS == 1 && !SCALED && !CAUSAL), "several heads per workgroup: the plain full-batch form only");
+    int bh = QS > 1 ? blockIdx.x / QS : blockIdx.x;
     const int qwave = QS > 1 ? (int)(blockIdx.x % QS) * NW + wave : wave;   // this wave's first query tile
     constexpr int QSTEP = NW * QS;                                          // ... and its stride
-    const int b = bh / H;
-    const int h = bh % H;
+    int b = bh / H;
+    int h = bh % H;
     const int C3 = 3 * H * DH;
     const bf16_t* base = qkv + (size_t)b * L * C3;
     const bf16_t* gq = base + h * DH;
     const bf16_t* gk = base + (H + h) * DH;
     const bf16_t* gv = base + (2 * H + h) * DH;
+    // next head's K / V on their way through registers: block c of 8 rows (K blocks first, then V) belongs to wave c % NW
+    constexpr int PF_BLOCKS = KROWS / 8 + VROWS / 8;
+    constexpr int PF_N = HPW > 1 ? (PF_BLOCKS + NW - 1) / NW : 1;           // 16-byte pieces per lane
+    constexpr int PF_TILES = (NT + NW - 1) / NW - 1 > 0 ? (NT + NW - 1) / NW - 1 : 1;   // query tiles every wave is sure to run
+    constexpr int PF_CHUNK = (PF_N + PF_TILES - 1) / PF_TILES;
+    uint4 pf[PF_N];
 
     // ---- stage K by LDS-DMA: one instruction = 8 rows x 128 B per wave; rows >= L re-read row L-1
     //      (their scores are masked below).  LDS image is lane-linear, the swizzle is on the source.
@@ -125,12 +139,57 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void attention_kernel(con
     };
     bf16x8 qf[2], qn[2];
     load_q(qwave < n_qt ? qwave : 0, qf);
+    // One wait for K and V.  "K first" (start the first tile's Q.K^T when K has landed, wait for V in front of the first P.V) was built
+    // in round 4 and is not here: with V's LDS-DMA still in flight the backend guards the K fragment reads with s_waitcnt vmcnt(0)
+    // (it cannot tell the two LDS regions apart), so the reads wait for V anyway unless every staging instruction AND the Q loads
+    // become inline asm; and the prize is small -- staging is HBM-bound (K + V of all heads at 6.5 TB/s), K first moves no byte and
+    // could cover only one query tile's Q.K^T phase per wave (~0.5 us of 39).
     __syncthreads();   // (drains the LDS-DMA queue) K, V^T, key scales visible
 
+#pragma unroll 1
+    for (int hh = 0; hh < HPW; ++hh) {
+    const int bh_next = bh + (int)gridDim.x;
+    const bool pf_on = HPW > 1 && hh + 1 < HPW && bh_next < BH;            // workgroup-uniform
+    const bf16_t* nbase = qkv + (size_t)(pf_on ? bh_next / H : b) * L * C3;
+    const bf16_t* nk = nbase + (H + (pf_on ? bh_next % H : h)) * DH;
+    const bf16_t* nv = nbase + (2 * H + (pf_on ? bh_next % H : h)) * DH;
+    // piece i of this lane: 16 bytes of row (c * 8 + lane / 8) of K (c < KROWS / 8) or V, the chunk the LDS image wants at position
+    // lane % 8.  Buffer loads: the lane's part of the address (row within the block, swizzled chunk -- the swizzle keys (r >> 1) & 7
+    // and (r >> 1) & 3 see only the block's parity, which is the wave's) is ONE 32-bit offset per operand, the block's rows go into the
+    // scalar offset; rows >= L are out of the descriptor's range and read as zeros (the LDS-DMA path repeats row L - 1 there: their
+    // scores are masked and their P is 0 either way).
+    const uint32_t row_b = (uint32_t)C3 * 2u;
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)nk, 0, (int)((uint32_t)(L - 1) * row_b + 128u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)nv, 0, (int)((uint32_t)(L - 1) * row_b + 128u), 0x00020000);
+    const int pr8 = lane >> 3, pcp = lane & 7;
+    const uint32_t voff_k = (uint32_t)pr8 * row_b + (uint32_t)((pcp ^ ((4 * wave + (pr8 >> 1)) & 7)) * 16);
+    const uint32_t voff_v = (uint32_t)pr8 * row_b + (uint32_t)(((((pcp >> 1) ^ ((pr8 >> 1) & 3)) << 1) | (pcp & 1)) * 16);
+    typedef uint32_t pf_u4 __attribute__((ext_vector_type(4)));
+    auto pf_load = [&](int i) {
+        const int c = i * NW + wave;
+        pf_u4 v = {0u, 0u, 0u, 0u};
+        if (c < KROWS / 8) v = __builtin_amdgcn_raw_buffer_load_b128(rs_k, voff_k, (uint32_t)(c * 8) * row_b, 0);
+        else if (c < PF_BLOCKS) v = __builtin_amdgcn_raw_buffer_load_b128(rs_v, voff_v, (uint32_t)((c - KROWS / 8) * 8) * row_b, 0);
+        pf[i] = make_uint4(v[0], v[1], v[2], v[3]);
+    };
+    int pf_it = 0;
 #pragma unroll 1
     for (int qt = qwave; qt < n_qt; qt += QSTEP) {
         const int q0 = qt * 16;
         load_q(qt + QSTEP < n_qt ? qt + QSTEP : qt, qn);       // prefetch the next tile's Q fragment
+        if constexpr (HPW > 1) {
+            // one chunk of the next head's rows per query tile, behind this tile's Q prefetch (the loads retire in order: the wait for
+            // the Q fragment at the top of the next tile leaves this chunk in flight)
+            if (pf_on) {
+#pragma unroll
+                for (int t = 0; t < PF_TILES; ++t)
+                    if (pf_it == t) {
+#pragma unroll
+                        for (int i = t * PF_CHUNK; i < (t + 1) * PF_CHUNK && i < PF_N; ++i) pf_load(i);
+                    }
+            }
+            ++pf_it;
+        }
         // the K fragments are the same for every query tile: stop the compiler from hoisting all
         // 2*NT of them out of this loop (136+ VGPRs -> scratch spills); LDS re-reads are the point
         int lds_k = 0;
@@ -288,6 +347,24 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void attention_kernel(con
         qf[0] = qn[0];
         qf[1] = qn[1];
     }
+    if constexpr (HPW > 1) {
+        if (!pf_on) break;
+        // next head: its first Q fragment, then its K / V rows from the registers into the LDS image (same layout as the LDS-DMA's)
+        bh = bh_next;
+        b = bh / H;
+        h = bh % H;
+        base = qkv + (size_t)b * L * C3;
+        gq = base + h * DH;
+        load_q(qwave < n_qt ? qwave : 0, qf);
+        __syncthreads();                               // every wave is done with the current head's K and V
+#pragma unroll
+        for (int i = 0; i < PF_N; ++i) {
+            const int c = i * NW + wave;
+            if (c < PF_BLOCKS) *(uint4*)(smem + (size_t)c * 8 * KROW_BYTES + lane * 16) = pf[i];     // sV follows sK: block c of the pair
+        }
+        __syncthreads();
+    }
+    }
 }
 
 template <int NT, int LC, bool SCALED, int NW>
@@ -301,20 +378,43 @@ int launch_attn2(const bf16_t* qkv, const float* ks, bf16_t* out, int B, int L, 
     constexpr int QSMALL = (NT + NW - 1) / NW;
     if (B * H <= 64) {
         US_TRY(us_opt_in_lds((const void*)attention_kernel<NT, LC, SCALED, NW, false, QSMALL>, 160 * 1024, lds_ok_q4));
-        hipLaunchKernelGGL((attention_kernel<NT, LC, SCALED, NW, false, QSMALL>), dim3(B * H * QSMALL), dim3(64 * NW), lds, s, qkv, ks, out, L, H);
+        hipLaunchKernelGGL((attention_kernel<NT, LC, SCALED, NW, false, QSMALL>), dim3(B * H * QSMALL), dim3(64 * NW), lds, s, qkv, ks, out, L, H, B * H);
         us_rec_end(rec, s);
         US_CHECK_LAUNCH();
         return USPACE_OK;
     }
     if (B * H <= 128) {         // half of the CUs: two (12.1 -> 8.9 us at B * H = 128; three: no faster; nothing above that)
         US_TRY(us_opt_in_lds((const void*)attention_kernel<NT, LC, SCALED, NW, false, 2>, 160 * 1024, lds_ok_q2));
-        hipLaunchKernelGGL((attention_kernel<NT, LC, SCALED, NW, false, 2>), dim3(B * H * 2), dim3(64 * NW), lds, s, qkv, ks, out, L, H);
+        hipLaunchKernelGGL((attention_kernel<NT, LC, SCALED, NW, false, 2>), dim3(B * H * 2), dim3(64 * NW), lds, s, qkv, ks, out, L, H, B * H);
         us_rec_end(rec, s);
         US_CHECK_LAUNCH();
         return USPACE_OK;
     }
+    if constexpr (!SCALED && NW == 8) {
+        // (measured: L = 334 at B * H = 1024 60.8 -> 54.8 us; the 4-wave form of L = 257, two workgroups per CU whose rounds overlap by
+        // themselves, 39.1 -> 39.4 us: not taken there)
+        // more heads than resident workgroups (one per CU for the 8-wave form): one workgroup walks
+        // `rounds` heads and fetches the next head's K / V through registers under the current head's query tiles
+        constexpr int SLOTS = 256;
+        const int rounds = us_cdiv(B * H, SLOTS);
+        static std::atomic<uint64_t> lds_ok_h2{0}, lds_ok_h4{0};
+        if (rounds == 2) {
+            US_TRY(us_opt_in_lds((const void*)attention_kernel<NT, LC, false, NW, false, 1, 2>, 160 * 1024, lds_ok_h2));
+            hipLaunchKernelGGL((attention_kernel<NT, LC, false, NW, false, 1, 2>), dim3(us_cdiv(B * H, 2)), dim3(64 * NW), lds, s, qkv, ks, out, L, H, B * H);
+            us_rec_end(rec, s);
+            US_CHECK_LAUNCH();
+            return USPACE_OK;
+        }
+        if (rounds == 3 || rounds == 4) {
+            US_TRY(us_opt_in_lds((const void*)attention_kernel<NT, LC, false, NW, false, 1, 4>, 160 * 1024, lds_ok_h4));
+            hipLaunchKernelGGL((attention_kernel<NT, LC, false, NW, false, 1, 4>), dim3(us_cdiv(B * H, rounds)), dim3(64 * NW), lds, s, qkv, ks, out, L, H, B * H);
+            us_rec_end(rec, s);
+            US_CHECK_LAUNCH();
+            return USPACE_OK;
+        }
+    }
     US_TRY(us_opt_in_lds((const void*)attention_kernel<NT, LC, SCALED, NW>, 160 * 1024, lds_ok));
-    hipLaunchKernelGGL((attention_kernel<NT, LC, SCALED, NW>), dim3(B * H), dim3(64 * NW), lds, s, qkv, ks, out, L, H);
+    hipLaunchKernelGGL((attention_kernel<NT, LC, SCALED, NW>), dim3(B * H), dim3(64 * NW), lds, s, qkv, ks, out, L, H, B * H);
     us_rec_end(rec, s);
     US_CHECK_LAUNCH();
     return USPACE_OK;
@@ -331,7 +431,7 @@ template <int NT>
 int launch_attn_causal(const bf16_t* qkv, bf16_t* out, int B, int L, int H, hipStream_t s) {
     constexpr int NP = (NT + 1) / 2;
     const size_t lds = (size_t)NT * 16 * KROW_BYTES + (size_t)NP * 32 * KROW_BYTES;
-    hipLaunchKernelGGL((attention_kernel<NT, 0, false, 4, true>), dim3(B * H), dim3(256), lds, s, qkv, nullptr, out, L, H);
+    hipLaunchKernelGGL((attention_kernel<NT, 0, false, 4, true>), dim3(B * H), dim3(256), lds, s, qkv, nullptr, out, L, H, B * H);
     US_CHECK_LAUNCH();
     return USPACE_OK;
 }
