@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define USPACE_ABI_VERSION 8
+#define USPACE_ABI_VERSION 9
 
 #define USPACE_OK 0
 #define USPACE_ERR_ARG (-1)         /* bad pointer / size / unsupported shape */
@@ -51,6 +51,7 @@ USPACE_API int uspace_abi_version(void);
 #define USPACE_EPI_OUT_BF16 16   /* write out_bf16[M,N]                         */
 #define USPACE_EPI_CEN_OUT 32    /* uspace_gemm_bf16_ext: also write bf16(v - row_c[m]) and per-row partial sums */
 #define USPACE_EPI_LN_IN 64      /* uspace_gemm_bf16_ext: A holds centred rows; apply LayerNorm through the GEMM  */
+#define USPACE_EPI_RANK1 128     /* uspace_gemm_bf16_ext, with CEN_OUT: + row_add[m] * col_add[n] (a K slab that was stored centred) */
 
 /* nn.Linear on bf16 operands with fp32 accumulation on the MFMA cores:
  *     acc[M,N] = [A | A2][M,K] . W[N,K]^T
@@ -87,6 +88,11 @@ typedef struct uspace_gemm_ext {
     float* c_out;           /* [M] or NULL */
     int norm_dim;           /* LayerNorm width (row length of the producer's output) */
     float eps;
+    /* USPACE_EPI_RANK1: acc[m, n] += row_add[m] * col_add[n] ahead of the bias.  skip_linear(cat([x, skip])) with the skip kept as
+     * the CENTRED bf16 copy its producer wrote anyway (skip = xc + c):  xc . W2^T + c[m] * rowsum(W2)[n]  -- row_add = the centring
+     * constants of that copy, col_add[n] = sum_k bf16(W[n, K1 + k]) (libs/uvit.py:158-159). */
+    const float* row_add;   /* [M] */
+    const float* col_add;   /* [N] */
     /* optional (any epilogue without LN_IN / GELU): workspace for the K-split form of small launches -- few output tiles and
      * a long K are cut into K ranges on as many times the CUs, whose fp32 partial sums go here; a second kernel adds them in
      * a fixed order and applies the epilogue.  uspace_gemm_split_ws_bytes(M, N, K) is the size it needs (0: the launch is

@@ -521,6 +521,55 @@ def test_layernorm_folded_through_gemms(hip, M, D, Kp, N2):
                                 None, 0, hip.ptr(y), N2, hip.stream_ptr()) != 0
 
 
+@pytest.mark.parametrize("M,D", [(64 * 257, 1024), (32 * 257, 1024), (4 * 257, 512), (4 * 257, 1024), (515, 256), (64 * 334, 512)])
+def test_skip_linear_with_a_centred_skip_slab(hip, M, D):
+    """skip_linear(cat([x, skip])) (libs/uvit.py:158-159) with the skip stored as the centred bf16 copy its producer wrote for the
+    next norm (skip_c = bf16(skip - c)): two K slabs + the rank-1 epilogue term c[m] * rowsum(bf16(W[:, D:]))[n] (USPACE_EPI_RANK1) on
+    every tile form the planner picks, against the fp32 result of the concat, and the producer side outputs (centred copy, partial
+    sums) of the same launch."""
+    import ctypes
+    rng = np.random.default_rng(M + D)
+    xcur = bf16_round(_rand(rng, M, D))
+    skip = (_rand(rng, M, D) + _rand(rng, M, 1) * 3.0).astype(np.float32)          # rows with large, different means
+    c = (skip.mean(axis=1) + 0.05 * _rand(rng, M)).astype(np.float32)             # centring constants: close to the row means
+    skip_c = bf16_round(skip - c[:, None])
+    W = bf16_round(_rand(rng, D, 2 * D) * 0.05)
+    b = _rand(rng, D)
+    rows = np.unique(np.concatenate([rng.integers(0, M, 500), np.arange(min(M, 260)), np.arange(max(M - 300, 0), M)]))
+    ref = C.linear(np.concatenate([xcur[rows], skip_c[rows] + c[rows, None]], axis=1), W, b)
+    lib = hip.lib()
+    slots = lib.uspace_gemm_part_slots_k(M, D, 2 * D)
+    cs2 = W[:, D:].sum(axis=1).astype(np.float32)
+    dx, ds, dW, db = to_dev(xcur, torch.bfloat16), to_dev(skip_c, torch.bfloat16), to_dev(W, torch.bfloat16), to_dev(b)
+    drc = to_dev(_rand(rng, M) * 0.1)                       # this launch's own centring constants (producer role)
+    dc, dcs2 = to_dev(c), to_dev(cs2)
+    out = torch.empty(M, D, device="cuda")
+    xc = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+    part = torch.full((M, slots, 2), float("nan"), device="cuda")
+    ext = hip.GemmExt(hip.ptr(drc).value, hip.ptr(xc).value, D, hip.ptr(part).value, None, 0, None, None, D, 1e-5)
+    ext.row_add, ext.col_add = hip.ptr(dc).value, hip.ptr(dcs2).value
+    ws_bytes = lib.uspace_gemm_split_ws_bytes(M, D, 2 * D)
+    ws = torch.zeros(max(ws_bytes // 4, 4), device="cuda")
+    ext.split_ws, ext.split_ws_bytes = hip.ptr(ws).value, ws_bytes
+    flags = hip.EPI_RANK1 | hip.EPI_CEN_OUT | hip.EPI_BIAS | hip.EPI_OUT_F32
+    rc = lib.uspace_gemm_bf16_ext(hip.ptr(dx), D, hip.ptr(ds), D, D, hip.ptr(dW), 2 * D, M, D, 2 * D, flags, hip.ptr(db), None, 0,
+                                  hip.ptr(out), D, None, 0, ctypes.byref(ext), hip.stream_ptr())
+    assert rc == 0
+    og = out.cpu().numpy()
+    np.testing.assert_allclose(og[rows], ref, rtol=2e-4, atol=2e-3)
+    assert torch.equal(xc, (out - drc[:, None]).to(torch.bfloat16))
+    pg = part.cpu().numpy().astype(np.float64).sum(axis=1)
+    cen = og.astype(np.float64) - drc.cpu().numpy()[:, None]
+    np.testing.assert_allclose(pg[:, 0], cen.sum(1), rtol=1e-4, atol=2e-2)
+    np.testing.assert_allclose(pg[:, 1], (cen ** 2).sum(1), rtol=1e-4)
+    # the flag needs its operands and a producer launch
+    bad = hip.GemmExt(hip.ptr(drc).value, hip.ptr(xc).value, D, hip.ptr(part).value, None, 0, None, None, D, 1e-5)
+    assert lib.uspace_gemm_bf16_ext(hip.ptr(dx), D, hip.ptr(ds), D, D, hip.ptr(dW), 2 * D, M, D, 2 * D, flags, hip.ptr(db), None, 0,
+                                    hip.ptr(out), D, None, 0, ctypes.byref(bad), hip.stream_ptr()) != 0
+    assert lib.uspace_gemm_bf16_ext(hip.ptr(dx), D, hip.ptr(ds), D, D, hip.ptr(dW), 2 * D, M, D, 2 * D, hip.EPI_RANK1 | hip.EPI_BIAS | hip.EPI_OUT_F32,
+                                    hip.ptr(db), None, 0, hip.ptr(out), D, None, 0, ctypes.byref(ext), hip.stream_ptr()) != 0
+
+
 @pytest.mark.parametrize("M,N,K,kind", [
     (4 * 257, 1536, 512, "ln_in"),          # U-ViT-S qkv at batch 4 (BASELINE config 1): consumer of the folded LayerNorm
     (4 * 257, 2048, 512, "bias_gelu_bf16"),  # fc1 shape

@@ -12,9 +12,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libuspace_hip.so")
 
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_OUT_BF16 = 1, 2, 4, 8, 16
-EPI_CEN_OUT, EPI_LN_IN = 32, 64          # uspace_gemm_bf16_ext only (LayerNorm folded through the GEMMs)
+EPI_CEN_OUT, EPI_LN_IN, EPI_RANK1 = 32, 64, 128          # uspace_gemm_bf16_ext only (LayerNorm folded through the GEMMs)
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _ERR = {-1: "USPACE_ERR_ARG", -2: "USPACE_ERR_LAUNCH", -3: "USPACE_ERR_WORKSPACE"}
 
@@ -51,6 +51,7 @@ class GemmExt(ctypes.Structure):
     _fields_ = [("row_c", ctypes.c_void_p), ("out_cen", ctypes.c_void_p), ("ld_cen", ctypes.c_int),
                 ("part_out", ctypes.c_void_p), ("part_in", ctypes.c_void_p), ("np_in", ctypes.c_int),
                 ("colsum", ctypes.c_void_p), ("c_out", ctypes.c_void_p), ("norm_dim", ctypes.c_int), ("eps", ctypes.c_float),
+                ("row_add", ctypes.c_void_p), ("col_add", ctypes.c_void_p),
                 ("split_ws", ctypes.c_void_p), ("split_ws_bytes", ctypes.c_size_t)]
 
 

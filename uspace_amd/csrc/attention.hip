@@ -390,7 +390,7 @@ int launch_attn2(const bf16_t* qkv, const float* ks, bf16_t* out, int B, int L, 
         US_CHECK_LAUNCH();
         return USPACE_OK;
     }
-    if constexpr (!SCALED && NW == 8) {
+    if constexpr (!SCALED && NW == 8 && LC > 0) {     // (the generic-length instantiation spills with the prefetch registers)
         // (measured: L = 334 at B * H = 1024 60.8 -> 54.8 us; the 4-wave form of L = 257, two workgroups per CU whose rounds overlap by
         // themselves, 39.1 -> 39.4 us: not taken there)
         // more heads than resident workgroups (one per CU for the 8-wave form): one workgroup walks

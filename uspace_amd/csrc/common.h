@@ -145,6 +145,9 @@ int us_head_pack(const float* norm_g, const float* norm_b, const float* dec_w, c
 int us_output_head_packed(const float* tok, int L, int extras, const float* image, const float* conv_w, const float* conv_b,
                           float* scratch, float* out, int B, int C, int S, int p, int D, float eps, hipStream_t s);
 
+// out[n] = sum_k float(bf16(W[n * ld + col0 + k])), k < ncols (rowops.hip; pack-time companion of USPACE_EPI_RANK1)
+int us_rowsum_bf16(const float* W, int ld, int col0, int ncols, float* out, int N, hipStream_t s);
+
 // Opt a kernel in to more than 64 KiB of dynamic LDS.  The attribute is per DEVICE: `done` (one per kernel, static at the
 // launch site) records the devices already served as a bit mask, so a process that drives several GPUs sets it on each
 // of them, and concurrent host threads at worst set it twice.  Devices >= 64 set it on every launch.

@@ -46,6 +46,8 @@ struct GemmArgs {
     const float* part_in;
     const float* colsum;
     float* c_out;
+    const float* row_add;   // USPACE_EPI_RANK1: acc[m][n] += row_add[m] * col_add[n]
+    const float* col_add;
     int ld_cen, np_in;
     float inv_d, eps;
     int wide;   // bf16 outputs (out_bf16, out_cen) allow 16-byte stores: row strides % 8 == 0, bases 16-byte aligned
@@ -366,9 +368,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
     // before the K loop: their launches are a few K tiles long, and a dependent global load after the loop is 1-2 us of a
     // 10 us kernel; the 256-row, 256-column forms have no registers to spare for that and K loops long enough not to care
     constexpr bool LN_IN = (FLAGS & USPACE_EPI_LN_IN) != 0, CEN = (FLAGS & USPACE_EPI_CEN_OUT) != 0;
+    constexpr bool RK1 = (FLAGS & USPACE_EPI_RANK1) != 0;    // + row_add[m] * col_add[n]: the row value rides in the producers' parked pair
+    static_assert(!RK1 || (CEN && !LN_IN), "the rank-1 term belongs to a LayerNorm producer (skip_linear)");
+    constexpr bool CSV = LN_IN || RK1;                       // a per-column vector beside the bias (column sums / col_add)
     constexpr bool EARLY_EPI = BM * BN <= 256 * 128;
     f32x4 bias4[TN];
-    f32x4 cs4[LN_IN ? TN : 1];
+    f32x4 cs4[CSV ? TN : 1];
     auto load_epi_consts = [&]() {
         if constexpr (FLAGS & USPACE_EPI_BIAS) {
 #pragma unroll
@@ -378,12 +383,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
                 bias4[j] = *(const f32x4*)(g.bias + n);
             }
         }
-        if constexpr (LN_IN) {
+        if constexpr (CSV) {
+            const float* const cv = RK1 ? g.col_add : g.colsum;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 int n = n0 + wn * (BN / WN) + j * 16 + fq * 4;
                 n = n < g.N ? n : g.N - 4;
-                cs4[j] = *(const f32x4*)(g.colsum + n);
+                cs4[j] = *(const f32x4*)(cv + n);
             }
         }
     };
@@ -411,7 +417,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
     // behind the first LDS-DMA stages -- their latency overlaps the first tile's -- and parks them in LDS after the barrier
     // (ring form: before the stages, so that the counted wait for the first tile covers them)
     float2 pr[ROWV ? 8 : 1];
-    float rc_v = 0.f;
+    float rc_v = 0.f, ra_v = 0.f;
     int rv_m = -1;
     auto fetch_rowv = [&]() {
         static_assert(BM + 16 <= THREADS || !ROWV, "one thread per tile row");
@@ -429,6 +435,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
                     if (n0 == 0 && g.c_out) rc_v = g.row_c[m];
                 } else {
                     rc_v = g.row_c[m];
+                    if constexpr (RK1) ra_v = g.row_add[m];
                 }
             }
         }
@@ -476,7 +483,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
                     v = make_float2(d, rsqrtf(fmaxf(s2 * g.inv_d - d * d, 0.f) + g.eps));
                     if (n0 == 0 && g.c_out) g.c_out[rv_m] = rc_v + d;     // N tile 0 publishes the row mean
                 } else {
-                    v = make_float2(rc_v, 0.f);
+                    v = make_float2(rc_v, ra_v);
                 }
             }
             // read in the epilogue, many barriers later
@@ -721,7 +728,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
     // ---- epilogue: lane holds, for sub-tile (i,j), row m = ..+fr and columns n = ..+4*fq+{0,1,2,3}
     if constexpr (!EARLY_EPI) load_epi_consts();
     float ps1 = 0.f, ps2 = 0.f;   // producer: running partial sums of the row being emitted
-    float row_d = 0.f, row_r = 1.f, row_cv = 0.f;
+    float row_d = 0.f, row_r = 1.f, row_cv = 0.f, row_a = 0.f;
     // one accumulator vector = 4 consecutive columns of one row: value (LayerNorm finish, bias), activation, outputs
     auto emit_pre = [&](f32x4 v, const f32x4& b, const f32x4& cs) -> f32x4 {
         // rstd * (acc - d * colsum) + bias as two fused multiply-adds per value: acc * rstd + (bias - (d * rstd) * colsum)
@@ -729,6 +736,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
             const float dr = -row_d * row_r;
             if constexpr (FLAGS & USPACE_EPI_BIAS) return v * row_r + (cs * dr + b);
             else return v * row_r + cs * dr;
+        }
+        if constexpr (RK1) {
+            if constexpr (FLAGS & USPACE_EPI_BIAS) return v + (cs * row_a + b);
+            else return v + cs * row_a;
         }
         if constexpr (FLAGS & USPACE_EPI_BIAS) v += b;
         return v;
@@ -795,6 +806,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
             row_cv = rv[ri].x;
             ps1 = ps2 = 0.f;
         }
+        if constexpr (RK1) row_a = rv[ri].y;
     };
     auto row_end = [&](int m, bool valid, int lrow, int slot) {
         if constexpr (CEN) {
@@ -830,7 +842,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
             // the TN vectors of a row go through the activation together (TN x 4 independent chains)
             f32x4 v[TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) v[j] = emit_pre(acc[i][j], bias4[j], cs4[LN_IN ? j : 0]);
+            for (int j = 0; j < TN; ++j) v[j] = emit_pre(acc[i][j], bias4[j], cs4[CSV ? j : 0]);
 #if !USPACE_ABLATE_NOGELU
             if constexpr (FLAGS & USPACE_EPI_GELU) gelu_erf_batch<TN>(v);
 #endif
@@ -875,7 +887,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
                 for (int j = 0; j < TN; ++j) {
                     const int n = n0 + wn * (BN / WN) + j * 16 + fq * 4;
                     if (n >= g.N) continue;
-                    emit(acc[i][j], bias4[j], m, n, cs4[LN_IN ? j : 0]);
+                    emit(acc[i][j], bias4[j], m, n, cs4[CSV ? j : 0]);
                 }
             }
             row_end(m, vrow, wm * (BM / WM) + i * 16 + fr, wn);
@@ -891,7 +903,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
                 const int n = n0 + wn * (BN / WN) + (wm * XN + j) * 16 + fq * 4;
                 if (n < g.N) {
                     f32x4 csx = cs4[0];
-                    if constexpr (LN_IN) csx = pick_b<WM, XN>(cs4, wm, j);
+                    if constexpr (CSV) csx = pick_b<WM, XN>(cs4, wm, j);
                     emit(xacc[j], pick_b<WM, XN>(bias4, wm, j), m, n, csx);
                 }
             }
@@ -1034,6 +1046,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* ws, int
             v = sp < S ? w : v;
         }
         if (flags & USPACE_EPI_RESIDUAL) v += *(const f32x4*)(g.resid + (size_t)m * g.ld_resid + n);
+        if (flags & USPACE_EPI_RANK1) v += *(const f32x4*)(g.col_add + n) * g.row_add[m];
         if (flags & USPACE_EPI_BIAS) v += *(const f32x4*)(g.bias + n);
         if (flags & USPACE_EPI_OUT_F32) *(f32x4*)(g.out_f32 + (size_t)m * g.ld_f32 + n) = v;
         if (flags & USPACE_EPI_OUT_BF16) {
@@ -1224,7 +1237,7 @@ int dispatch_tile(const GemmArgs& a, hipStream_t s) {
 
 int dispatch_flags(const GemmArgs& g, int epi_flags, hipStream_t s) {
     constexpr int B_ = USPACE_EPI_BIAS, G_ = USPACE_EPI_GELU, R_ = USPACE_EPI_RESIDUAL,
-                  F_ = USPACE_EPI_OUT_F32, H_ = USPACE_EPI_OUT_BF16, C_ = USPACE_EPI_CEN_OUT, L_ = USPACE_EPI_LN_IN;
+                  F_ = USPACE_EPI_OUT_F32, H_ = USPACE_EPI_OUT_BF16, C_ = USPACE_EPI_CEN_OUT, L_ = USPACE_EPI_LN_IN, K_ = USPACE_EPI_RANK1;
     switch (epi_flags) {
         case H_:                return dispatch_tile<H_>(g, s);                 // qkv
         case B_ | H_:           return dispatch_tile<B_ | H_>(g, s);
@@ -1240,6 +1253,7 @@ int dispatch_flags(const GemmArgs& g, int epi_flags, hipStream_t s) {
         case C_ | B_ | R_ | F_:      return dispatch_tile<C_ | B_ | R_ | F_>(g, s);       // proj / fc2 feeding a norm
         case C_ | B_ | R_ | F_ | H_: return dispatch_tile<C_ | B_ | R_ | F_ | H_>(g, s);  // ... + raw bf16 copy (skip stack)
         case C_ | B_ | F_:           return dispatch_tile<C_ | B_ | F_>(g, s);            // skip_linear feeding norm1
+        case K_ | C_ | B_ | F_:      return dispatch_tile<K_ | C_ | B_ | F_>(g, s);       // ... whose skip slab was stored centred
         default:                return USPACE_ERR_ARG;
     }
 }
@@ -1345,6 +1359,7 @@ extern "C" int uspace_gemm_bf16_ext(const uint16_t* A, int lda, const uint16_t* 
         while ((1 << g.k1_log2) < K1) ++g.k1_log2;
     }
     g.row_c = nullptr; g.out_cen = nullptr; g.part_out = nullptr; g.part_in = nullptr; g.colsum = nullptr; g.c_out = nullptr;
+    g.row_add = nullptr; g.col_add = nullptr;
     g.ld_cen = 0; g.np_in = 0; g.inv_d = 0.f; g.eps = 0.f;
     g.wide = 0;
     g.nk_split = 0; g.split_stride = 0; g.split_ws = nullptr; g.split_ws_bytes = 0;
@@ -1353,11 +1368,15 @@ extern "C" int uspace_gemm_bf16_ext(const uint16_t* A, int lda, const uint16_t* 
         if (g.split_ws && ((uintptr_t)g.split_ws & 15)) return USPACE_ERR_ARG;
         g.row_c = ext->row_c; g.out_cen = ext->out_cen; g.ld_cen = ext->ld_cen; g.part_out = ext->part_out;
         g.part_in = ext->part_in; g.np_in = ext->np_in; g.colsum = ext->colsum; g.c_out = ext->c_out;
+        g.row_add = ext->row_add; g.col_add = ext->col_add;
         g.inv_d = ext->norm_dim > 0 ? 1.0f / (float)ext->norm_dim : 0.f;
         g.eps = ext->eps;
     }
     if (epi_flags & USPACE_EPI_CEN_OUT) {
         if (!g.row_c || !g.out_cen || !g.part_out || (g.ld_cen & 3)) return USPACE_ERR_ARG;
+    }
+    if (epi_flags & USPACE_EPI_RANK1) {
+        if (!(epi_flags & USPACE_EPI_CEN_OUT) || !g.row_add || !g.col_add) return USPACE_ERR_ARG;
     }
     if (epi_flags & USPACE_EPI_LN_IN) {
         if (!g.part_in || g.np_in <= 0 || g.np_in > 8 || !g.colsum || g.inv_d <= 0.f || (g.c_out && !g.row_c)) return USPACE_ERR_ARG;
@@ -1371,7 +1390,7 @@ extern "C" int uspace_gemm_bf16(const uint16_t* A, int lda, const uint16_t* A2, 
                                 const float* bias, const float* resid_in, int ld_resid,
                                 float* out_f32, int ld_f32, uint16_t* out_bf16, int ld_bf16,
                                 uspace_stream_t stream) {
-    if (epi_flags & (USPACE_EPI_CEN_OUT | USPACE_EPI_LN_IN)) return USPACE_ERR_ARG;
+    if (epi_flags & (USPACE_EPI_CEN_OUT | USPACE_EPI_LN_IN | USPACE_EPI_RANK1)) return USPACE_ERR_ARG;
     return uspace_gemm_bf16_ext(A, lda, A2, lda2, K1, W, ldw, M, N, K, epi_flags, bias, resid_in, ld_resid, out_f32, ld_f32,
                                 out_bf16, ld_bf16, nullptr, stream);
 }
@@ -1402,8 +1421,9 @@ extern "C" int uspace_gemm_slabs_bf16(const uint16_t* A, int lda, const uint16_t
     while ((1 << g.k1_log2) < K1) ++g.k1_log2;
     for (int i = 0; i < 9; ++i) g.slab_shift[i] = i < n_slab ? row_shift[i] : 0;
     g.row_c = nullptr; g.out_cen = nullptr; g.part_out = nullptr; g.part_in = nullptr; g.colsum = nullptr; g.c_out = nullptr;
+    g.row_add = nullptr; g.col_add = nullptr;
     g.ld_cen = 0; g.np_in = 0; g.inv_d = 0.f; g.eps = 0.f;
-    if (epi_flags & (USPACE_EPI_CEN_OUT | USPACE_EPI_LN_IN)) return USPACE_ERR_ARG;
+    if (epi_flags & (USPACE_EPI_CEN_OUT | USPACE_EPI_LN_IN | USPACE_EPI_RANK1)) return USPACE_ERR_ARG;
     g.nk_split = 0; g.split_stride = 0; g.split_ws = nullptr; g.split_ws_bytes = 0;
     g.wide = wide_ok(g, epi_flags);
     return dispatch_flags(g, epi_flags, (hipStream_t)stream);

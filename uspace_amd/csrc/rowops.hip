@@ -91,6 +91,19 @@ __global__ __launch_bounds__(256) void fold_ln_kernel(const float* __restrict__ 
     }
 }
 
+// out[n] = sum_k float(bf16(W[n, col0 + k])), k < ncols: the rank-1 companion of a K slab whose activations were stored centred
+// (skip_linear's second slab, uvit.hip) -- of the ROUNDED weights, which are what the MFMA multiplies.  One block per n.
+__global__ __launch_bounds__(256) void rowsum_bf16_kernel(const float* __restrict__ W, int ld, int col0, int ncols, float* __restrict__ out) {
+    __shared__ float red[4];
+    const int n = blockIdx.x;
+    float cs = 0.f;
+    for (int k = threadIdx.x; k < ncols; k += 256) cs += bf2f(f2bf(W[(size_t)n * ld + col0 + k]));
+    cs = wave_sum(cs);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cs;
+    __syncthreads();
+    if (threadIdx.x == 0) out[n] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // LayerNorm folding, first norm of a forward: rows centred by their own mean.  xc = bf16(x - mean), c = mean,
 // part[m] = (sum(x - mean), sum((x - mean)^2)) as a single partial-sum slot.  One wave per row (as layernorm_kernel).
 template <int NV>
@@ -813,6 +826,13 @@ extern "C" int uspace_fold_layernorm(const float* W, const float* gamma, const f
                                      float* bias_out, float* colsum, int N, int K, uspace_stream_t stream) {
     if (!W || !gamma || !beta || !Wf || !bias_out || !colsum || N <= 0 || K <= 0) return USPACE_ERR_ARG;
     hipLaunchKernelGGL(fold_ln_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, W, gamma, beta, bias, Wf, bias_out, colsum, K);
+    US_CHECK_LAUNCH();
+    return USPACE_OK;
+}
+
+int us_rowsum_bf16(const float* W, int ld, int col0, int ncols, float* out, int N, hipStream_t s) {
+    if (!W || !out || N <= 0 || ncols <= 0 || col0 < 0 || col0 + ncols > ld) return USPACE_ERR_ARG;
+    hipLaunchKernelGGL(rowsum_bf16_kernel, dim3(N), dim3(256), 0, s, W, ld, col0, ncols, out);
     US_CHECK_LAUNCH();
     return USPACE_OK;
 }

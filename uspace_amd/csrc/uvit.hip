@@ -41,6 +41,7 @@ struct BlockIdx {
     // derived at pack time for the LayerNorm-folded path (not parameters): gamma-folded weights, beta-folded biases,
     // column sums of the folded bf16 weights
     int qkv_f, qkv_fb, qkv_cs, fc1_f, fc1_fb, fc1_cs;
+    int skip_cs2 = -1;   // out-blocks: row sums of bf16(skip_linear.weight[:, D:]) -- the skip slab is stored centred (uspace_uvit_forward)
 };
 
 struct Model {
@@ -116,13 +117,14 @@ Model build_model(const uspace_uvit_config& c) {
         b.fc1_f = m.lay.add(Hd * D, BF16);
         b.fc1_fb = m.lay.add(Hd, F32);
         b.fc1_cs = m.lay.add(Hd, F32);
+        if (b.skip_w >= 0) b.skip_cs2 = m.lay.add(D, F32);
     }
     if ((D & 31) == 0 && D <= 2048) m.head_img = m.lay.add((long)us_head_image_floats((int)D), F32);
     return m;
 }
 
 struct Workspace {
-    size_t x, xb, h, qkv, f, skips, ctx_bf, ctx_f32, head, xc, part, cbuf, splitk, splitk_bytes, total;
+    size_t x, xb, h, qkv, f, skips, ctx_bf, ctx_f32, head, xc, part, cbuf, cskip, splitk, splitk_bytes, total;
 };
 
 Workspace plan_workspace(const uspace_uvit_config& c, const Model& m, int B) {
@@ -142,6 +144,7 @@ Workspace plan_workspace(const uspace_uvit_config& c, const Model& m, int B) {
     w.xc = take(M * D * 2);                          // LayerNorm folding: centred bf16 copy of the residual stream
     w.part = take(M * (size_t)us_cdiv((int)D, 64) * 2 * 4);    // per-row partial sums, one slot per producer N tile (64 columns at the least)
     w.cbuf = take(M * 4);                            // per-row centring constants (row means at the last norm)
+    w.cskip = take((size_t)(c.depth / 2) * M * 4);   // ... of the centred copies kept on the long-skip stack, one per in-block
     // fp32 partial sums of the K-split form the GEMM uses for small batches (proj, skip_linear, fc2: N = D)
     w.splitk_bytes = std::max(std::max(uspace_gemm_split_ws_bytes((int)M, (int)D, (int)D), uspace_gemm_split_ws_bytes((int)M, (int)D, 2 * (int)D)),
                               uspace_gemm_split_ws_bytes((int)M, (int)D, c.mlp_hidden));
@@ -201,6 +204,7 @@ extern "C" int uspace_uvit_pack_weights(const uspace_uvit_config* cfg, const flo
                                      (float*)at(b.qkv_fb), (float*)at(b.qkv_cs), 3 * D, D, stream));
         US_TRY(uspace_fold_layernorm(params[b.fc1w], params[b.n2w], params[b.n2b], params[b.fc1b], (uint16_t*)at(b.fc1_f),
                                      (float*)at(b.fc1_fb), (float*)at(b.fc1_cs), Hd, D, stream));
+        if (b.skip_cs2 >= 0) US_TRY(us_rowsum_bf16(params[b.skip_w], 2 * D, D, D, (float*)at(b.skip_cs2), D, s));
     }
     if (m.head_img >= 0)
         US_TRY(us_head_pack(params[m.ng], params[m.nb], params[m.dw], params[m.db], cfg->patch_size * cfg->patch_size * cfg->in_chans, D,
@@ -300,38 +304,59 @@ extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* bl
         if (slots_skip <= 0 || slots_proj <= 0 || slots_fc2 <= 0) return USPACE_ERR_ARG;
         auto PFx = [&](int idx) { return (const float*)(wb + m.lay.p[idx].offset); };
         US_TRY(uspace_center_rows(x, xc, cbuf, part, M, D, stream));
-        int np = 1;                                   // partial-sum slots of whoever wrote xc last
+        int np = 1;                                   // partial-sum slots of whoever wrote the centred copy last
         uspace_gemm_ext prod{};                       // producers: centre by cbuf, write xc + part
         prod.row_c = cbuf; prod.out_cen = xc; prod.ld_cen = D; prod.part_out = part; prod.norm_dim = D; prod.eps = 1e-5f;
         prod.split_ws = plain.split_ws; prod.split_ws_bytes = plain.split_ws_bytes;
+        // The long skips are kept as the CENTRED bf16 copies the in-blocks' fc2 writes for the next norm anyway (round 4: the raw bf16
+        // copy beside it was one more 2 M D-byte store per in-block): in-block i's fc2 centres by cskip[i] -- the row means its own
+        // fc1 published there instead of into cbuf -- and writes straight into skip slot i, which is also what the next block's qkv
+        // reads.  skip_linear(cat([x, skip])) = x W1^T + (skip_c + cskip) W2^T: the second term's constant part is the rank-1 epilogue
+        // term cskip[m] * rowsum(W2)[n] (USPACE_EPI_RANK1; libs/uvit.py:158-159).
+        constexpr int K_ = USPACE_EPI_RANK1;
+        float* const cskip = (float*)(ws + w.cskip);
+        const uint16_t* cen_in = xc;                  // the centred copy the next consumer reads
+        const float* c_in = cbuf;                     // ... and the constants it was centred by
         for (int i = 0; i < m.nblocks; ++i) {
             const BlockIdx& b = m.blk[i];
             const bool is_in = i < half, is_out = i > half, is_last = i == m.nblocks - 1;
             if (is_out) {
-                const uint16_t* skip = skips + (size_t)(m.nblocks - 1 - i) * MD;
-                US_TRY(uspace_gemm_bf16_ext(xb, D, skip, D, D, PH(b.skip_w), 2 * D, M, D, 2 * D, C_ | B_ | F_, PF(b.skip_b),
-                                            nullptr, 0, x, D, nullptr, 0, &prod, stream));
+                const int si = m.nblocks - 1 - i;     // LIFO (libs/uvit.py:159,340)
+                uspace_gemm_ext pskip = prod;
+                pskip.row_add = cskip + (size_t)si * M;
+                pskip.col_add = PFx(b.skip_cs2);
+                US_TRY(uspace_gemm_bf16_ext(xb, D, skips + (size_t)si * MD, D, D, PH(b.skip_w), 2 * D, M, D, 2 * D, K_ | C_ | B_ | F_, PF(b.skip_b),
+                                            nullptr, 0, x, D, nullptr, 0, &pskip, stream));
                 np = slots_skip;
+                cen_in = xc;
+                c_in = cbuf;
             }
             uspace_gemm_ext cons{};
-            cons.row_c = cbuf; cons.c_out = cbuf; cons.part_in = part; cons.np_in = np; cons.norm_dim = D; cons.eps = 1e-5f;
+            cons.row_c = c_in; cons.c_out = cbuf; cons.part_in = part; cons.np_in = np; cons.norm_dim = D; cons.eps = 1e-5f;
             cons.colsum = PFx(b.qkv_cs);
-            US_TRY(uspace_gemm_bf16_ext(xc, D, nullptr, 0, D, PH(b.qkv_f), D, M, 3 * D, D, L_ | B_ | H_, PFx(b.qkv_fb), nullptr, 0,
+            US_TRY(uspace_gemm_bf16_ext(cen_in, D, nullptr, 0, D, PH(b.qkv_f), D, M, 3 * D, D, L_ | B_ | H_, PFx(b.qkv_fb), nullptr, 0,
                                         nullptr, 0, qkv, 3 * D, &cons, stream));
             const float* ks = io->key_scale ? io->key_scale + (size_t)i * B * L : nullptr;
             US_TRY(uspace_attention_bf16(qkv, ks, h, B, L, H, stream));
             US_TRY(uspace_gemm_bf16_ext(h, D, nullptr, 0, D, PH(b.projw), D, M, D, D, C_ | B_ | R_ | F_, PF(b.projb), x, D, x, D,
                                         nullptr, 0, &prod, stream));
             np = slots_proj;
+            cons.row_c = cbuf;
             cons.np_in = np;
             cons.colsum = PFx(b.fc1_cs);
+            if (is_in) cons.c_out = cskip + (size_t)i * M;      // the row means at norm2 of an in-block stay with its skip
             US_TRY(uspace_gemm_bf16_ext(xc, D, nullptr, 0, D, PH(b.fc1_f), D, M, Hd, D, L_ | B_ | G_ | H_, PFx(b.fc1_fb), nullptr, 0,
                                         nullptr, 0, f, Hd, &cons, stream));
             if (is_in) {
-                // the next block starts with a norm: centred copy + partials, plus the raw bf16 skip
-                US_TRY(uspace_gemm_bf16_ext(f, Hd, nullptr, 0, Hd, PH(b.fc2w), Hd, M, D, Hd, C_ | B_ | R_ | F_ | H_, PF(b.fc2b), x, D,
-                                            x, D, skips + (size_t)i * MD, D, &prod, stream));
+                // the next block starts with a norm: centred copy + partials -- written into the skip slot
+                uspace_gemm_ext pin = prod;
+                pin.row_c = cskip + (size_t)i * M;
+                pin.out_cen = skips + (size_t)i * MD;
+                US_TRY(uspace_gemm_bf16_ext(f, Hd, nullptr, 0, Hd, PH(b.fc2w), Hd, M, D, Hd, C_ | B_ | R_ | F_, PF(b.fc2b), x, D,
+                                            x, D, nullptr, 0, &pin, stream));
                 np = slots_fc2;
+                cen_in = skips + (size_t)i * MD;
+                c_in = cskip + (size_t)i * M;
             } else {
                 // mid / out blocks: the next consumer is skip_linear (raw bf16 xb) or the head (its own norm)
                 uint16_t* copy = is_last ? nullptr : xb;
