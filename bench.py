@@ -140,7 +140,8 @@ def roofline_rows(recs, D):
             byts += 4.0 * M * N * (bool(f & _hip.EPI_RESIDUAL) + bool(f & _hip.EPI_OUT_F32))
             byts += 2.0 * M * N * (bool(f & _hip.EPI_OUT_BF16) + bool(f & _hip.EPI_CEN_OUT))
             names = [nm for nm, bit in (("LN_IN", _hip.EPI_LN_IN), ("BIAS", _hip.EPI_BIAS), ("GELU", _hip.EPI_GELU), ("RESIDUAL", _hip.EPI_RESIDUAL),
-                                        ("OUT_F32", _hip.EPI_OUT_F32), ("OUT_BF16", _hip.EPI_OUT_BF16), ("CEN_OUT", _hip.EPI_CEN_OUT)) if f & bit]
+                                        ("OUT_F32", _hip.EPI_OUT_F32), ("OUT_BF16", _hip.EPI_OUT_BF16), ("CEN_OUT", _hip.EPI_CEN_OUT),
+                                        ("RANK1", _hip.EPI_RANK1)) if f & bit]
             row = dict(kernel="gemm_kernel", role=_gemm_role(f, N, K, D), epi="|".join(names), epi_flags=f, M=M, N=N, K=K)
         else:
             BH, L, hd = r["M"], r["N"], r["K"]
@@ -156,7 +157,7 @@ def roofline_rows(recs, D):
     return rows
 
 
-GEMM_SOURCES = ("gemm.hip", "common.h")
+GEMM_SOURCES = ("gemm.hip", "common.h")      # (tools/lab/gemm_chain.h is compiled only into lab variants)
 
 
 def fc1_traffic(model, B, tile):
