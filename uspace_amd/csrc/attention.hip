@@ -21,6 +21,15 @@
 // of the reference, tools/utils_t2i.py:196-224), i.e. it scales P before P.V but not the row sum.
 #include "common.h"
 
+// lab switch (tools/lab/build_variant.sh att_w4 attention.hip "-DUSPACE_ATT_W4=1"; measured in round 4 and not taken: 39.0 -> 43.5 us):
+// L = 257 on 8-wave workgroups, four waves per SIMD at 128 registers
+#if defined(USPACE_ATT_W4) && !USPACE_LAB
+#error "USPACE_ATT_W4 is a lab switch: build with tools/lab/build_variant.sh (-DUSPACE_LAB=1)"
+#endif
+#ifndef USPACE_ATT_W4
+#define USPACE_ATT_W4 0
+#endif
+
 namespace {
 
 constexpr int DH = 64;
@@ -55,8 +64,10 @@ __device__ __forceinline__ uint2 lds_read_tr16(const char* p) {
 // computes the current one (70 KB over 256 lanes = 18 x 16 B per lane; a handful per query tile, so that no wait of the tile loop
 // has more than a chunk behind it) and writes them to LDS between two barriers when the head is done: the same lane-linear image the
 // LDS-DMA of the first head produces, bit-equal results.
-template <int NT, int LC, bool SCALED, int NW, bool CAUSAL = false, int QS = 1, int HPW = 1>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void attention_kernel(const bf16_t* __restrict__ qkv,
+// W4: four waves per SIMD -- two 8-wave workgroups per CU (L <= 272: 70 KB of LDS each) at <= 128 registers; the K fragments are then
+// fetched two key tiles ahead instead of four (twice the waves cover the LDS latency).
+template <int NT, int LC, bool SCALED, int NW, bool CAUSAL = false, int QS = 1, int HPW = 1, bool W4 = false>
+__global__ __launch_bounds__(64 * NW, W4 ? 4 : 2) void attention_kernel(const bf16_t* __restrict__ qkv,
                                                            const float* __restrict__ key_scale,
                                                            bf16_t* __restrict__ out, int L_rt, int H, int BH) {
     const int L = LC > 0 ? LC : L_rt;
@@ -201,7 +212,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) void attention_kernel(con
         //      hide it).  Inside a group the k-slices are interleaved across tiles so consecutive MFMAs are independent.
         f32x4 s[NT];
         {
-            constexpr int TQ = 4, NQD = (NT + TQ - 1) / TQ;
+            constexpr int TQ = W4 ? 2 : 4, NQD = (NT + TQ - 1) / TQ;
             bf16x8 kb[2][TQ][2];
             auto load_kq = [&](int qd, bf16x8 (&dst)[TQ][2]) {
 #pragma unroll
@@ -413,6 +424,16 @@ int launch_attn2(const bf16_t* qkv, const float* ks, bf16_t* out, int B, int L, 
             return USPACE_OK;
         }
     }
+#if USPACE_ATT_W4
+    if constexpr (!SCALED && NW == 4 && LC > 0) {
+        static std::atomic<uint64_t> lds_ok_w4{0};
+        US_TRY(us_opt_in_lds((const void*)attention_kernel<NT, LC, false, 8, false, 1, 1, true>, 160 * 1024, lds_ok_w4));
+        hipLaunchKernelGGL((attention_kernel<NT, LC, false, 8, false, 1, 1, true>), dim3(B * H), dim3(512), lds, s, qkv, ks, out, L, H, B * H);
+        us_rec_end(rec, s);
+        US_CHECK_LAUNCH();
+        return USPACE_OK;
+    }
+#endif
     US_TRY(us_opt_in_lds((const void*)attention_kernel<NT, LC, SCALED, NW>, 160 * 1024, lds_ok));
     hipLaunchKernelGGL((attention_kernel<NT, LC, SCALED, NW>), dim3(B * H), dim3(64 * NW), lds, s, qkv, ks, out, L, H, B * H);
     us_rec_end(rec, s);
