@@ -38,6 +38,11 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #ifndef USPACE_CHAIN_SPLIT
 #define USPACE_CHAIN_SPLIT 0
 #endif
+// body-parity experiments (one tile per workgroup, all waves issue DMA): 1 = __syncthreads() as the K tile's barrier, 2 = no wrap-around
+// stage requests (the selects and the next-step descriptor arithmetic leave the loop), 4 = per-issue VGPR offsets instead of scalar offsets
+#ifndef USPACE_CHAIN_BODY
+#define USPACE_CHAIN_BODY 0
+#endif
 
 struct ChainArgs {
     int cg;        // column groups = chains per tile row (4)
@@ -114,13 +119,25 @@ __global__ __launch_bounds__(512, 1) void gemm_chain_kernel(const GemmArgs g, co
     // (LDS destinations and scalar offsets are derived from opaque copies inside each stage: written as plain constants the
     // compiler hoists all 34 of them out of the loops and keeps them in scalar registers, which then spill into vector lanes)
     const uint32_t smem_lds = (uint32_t)(uintptr_t)(US_LDS char*)smem;
+#if USPACE_CHAIN_BODY & 4
+    uint32_t a_offv[NISS], w_offv[NISS];
+#pragma unroll
+    for (int i = 0; i < NISS; ++i) {
+        a_offv[i] = a_voff + i * a_step;
+        w_offv[i] = w_voff + i * w_step;
+    }
+#endif
     auto stage_a = [&](int kt, int buf) {
         uint32_t lb = smem_lds + (uint32_t)(buf * STAGE_BYTES + wave_lds_off), st = a_step;
         asm volatile("" : "+s"(lb), "+s"(st));
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(gA + kt * BK), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int i = 0; i < NISS; ++i)
+#if USPACE_CHAIN_BODY & 4
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (US_LDS void*)(uintptr_t)(lb + i * ISS_ROWS * ROW_BYTES), 16, a_offv[i], 0, 0, 0);
+#else
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (US_LDS void*)(uintptr_t)(lb + i * ISS_ROWS * ROW_BYTES), 16, a_voff, i * st, 0, 0);
+#endif
         if constexpr (XTRA) {
             if (has_x && wave < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (US_LDS void*)(uintptr_t)(lb + TILE_A_BYTES + TILE_W_BYTES), 16, x_voff, 0, 0, 0);
         }
@@ -131,14 +148,22 @@ __global__ __launch_bounds__(512, 1) void gemm_chain_kernel(const GemmArgs g, co
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(gW + (size_t)n0 * g.ldw + kt * BK), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int i = 0; i < NISS; ++i)
+#if USPACE_CHAIN_BODY & 4
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (US_LDS void*)(uintptr_t)(lb + i * ISS_ROWS * ROW_BYTES), 16, w_offv[i], 0, 0, 0);
+#else
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (US_LDS void*)(uintptr_t)(lb + i * ISS_ROWS * ROW_BYTES), 16, w_voff, i * st, 0, 0);
+#endif
     };
     // the barrier of a K tile: P waves first wait for their LDS-DMA (the only vmcnt wait of the kernel's steady state; S waves have
     // stores in flight and must not), everyone for its LDS reads
     auto tile_barrier = [&]() {
+#if USPACE_CHAIN_BODY & 1
+        __syncthreads();
+#else
         if (dma_w) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#endif
     };
 
     const int fr = lane & 15, fq = lane >> 4;
@@ -287,15 +312,31 @@ __global__ __launch_bounds__(512, 1) void gemm_chain_kernel(const GemmArgs g, co
         // one loop body for all K tiles (the peeled form of gemm_kernel costs registers at the seams).  Stage requests of tile kt (P
         // waves): W of tile kt+1 at its start, A of tile kt+2 behind its barrier -- wrapping into the next step's first tile (buffer 0:
         // nk is even) for the last two tiles of a step.
+#if USPACE_CHAIN_BODY & 8
+        {   // the last K tile peeled: "there is a next tile" is a compile-time fact in the loop
+            int kt = 0;
+#pragma unroll 1
+            for (; kt + 1 < nk; ++kt) {
+                const bool wrap_a = kt + 2 >= nk;
+                CKTILE(kt, true, stage_w(kt + 1, (kt + 1) & 1, n0), if (!wrap_a || has_next) stage_a(wrap_a ? 0 : kt + 2, kt & 1))
+            }
+            CKTILE(kt, false, if (has_next) stage_w(0, 0, n_next), (void)0)
+        }
+#else
 #pragma unroll 1
         for (int kt = 0; kt < nk; ++kt) {
             const bool more = kt + 1 < nk;
             const bool wrap_w = !more, wrap_a = kt + 2 >= nk;
+#if USPACE_CHAIN_BODY & 2
+            CKTILE(kt, more, if (!wrap_w) stage_w(kt + 1, (kt + 1) & 1, n0), if (!wrap_a) stage_a(kt + 2, kt & 1))
+#else
             CKTILE(kt, more,
                    if (!wrap_w || has_next) stage_w(wrap_w ? 0 : kt + 1, (kt + 1) & 1, wrap_w ? n_next : n0),
                    if (!wrap_a || has_next) stage_a(wrap_a ? 0 : kt + 2, kt & 1))
+#endif
         }
 
+#endif
         // ---- epilogue.  Barrier E1: every wave has read the last K tile (buffer 1), which becomes the hand-over area.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
