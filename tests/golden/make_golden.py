@@ -502,6 +502,34 @@ def make_hooked_traj(uvit, uvit_t2i, m_u, x_u, m_t, x_t, ctx_t, timing, skip_lar
                 out[f"u_{tag}_files"] = np.frombuffer(json.dumps(list(reads)).encode(), dtype=np.uint8)
                 assert reads == [f"delta_{k / 100:.2f}.npy" for k in range(1, 41)], reads[:5]
             out["u_plain_x1"] = y_plain.numpy()
+            # mid block, DOCUMENTED SEMANTICS (the reference's reader raises on [n, L, D] tables, see make_hooks_u): the reference's own
+            # should_edit() and file naming decide per evaluation, the add x + table[ith] * scale is applied by a forward hook on the
+            # reference's mid_block; token-shaped tables mid_{t:.2f} drawn per time like the image-shaped ones
+            L_tok, D_emb = 65, 64
+            mid_files = []
+            cur = {}
+
+            def mid_hook(_m, _a, o):
+                digit = f"{cur['t']:.2f}"                                   # libs/dissection.py:120
+                if dis.should_edit(digit, 0.4):
+                    mid_files.append(f"delta_{digit}.npy")
+                    k = int(round(float(digit) * 100))
+                    tab = hooked_delta_table(k, (5, L_tok, D_emb))
+                    sel = torch.from_numpy(np.mean([tab[1], tab[3]], axis=0).astype(np.float32))
+                    return o + sel[None] * 6.0
+                return o
+
+            h = m_u.mid_block.register_forward_hook(mid_hook)
+            try:
+                with torch.no_grad():
+                    def fm(t, y):
+                        cur["t"] = t.expand(x_u.shape[0])[0].item()
+                        return m_u(y, t.expand(x_u.shape[0]), None, edit_loc=None)[0]
+                    y_mid, n = _euler(fm, x_u.clone(), 0.0, 1.0, 0.01)
+            finally:
+                h.remove()
+            assert n == 100 and mid_files == [f"delta_{k / 100:.2f}.npy" for k in range(1, 41)]
+            out["u_mid_x1"] = y_mid.numpy()
         finally:
             dis._read_npz_bcwh = orig
     # ---- (b)
@@ -545,6 +573,13 @@ def make_hooked_traj(uvit, uvit_t2i, m_u, x_u, m_t, x_t, ctx_t, timing, skip_lar
         assert n == 50
         timing["traj_L_t_B2_euler50_total_s"] = time.perf_counter() - t0
         out.update(Lt_z=z.numpy(), Lt_ctx=ctx.numpy(), Lt_x1_euler50=x1.numpy(), Lt_sha256=np.frombuffer(sd_sha256(m).encode(), dtype=np.uint8))
+        del m
+        # BASELINE configs[3]: U-ViT-S-deep16 T2I, 50 Euler steps (B = 2 of the 512)
+        m = build_big(uvit, uvit_t2i, "S", "t")
+        with torch.no_grad():
+            x1s, n = _euler(lambda t, y: m(y, t.expand(B), context=ctx)[0], z.clone(), 0.0, 1.0, 0.02)
+        assert n == 50
+        out.update(St_x1_euler50=x1s.numpy())
         del m
     save("hooked_traj.npz", **out)
 

@@ -348,7 +348,7 @@ def test_cnf_hooked_uncond_solves_match_reference_trajectories(golden_dir, tmp_p
     """hooked_traj.npz (a): the reference network + the reference's dissect_helper_uvit over 100 Euler steps (make_golden.py::
     make_hooked_traj).  The same solve through CNF.decode: end state within the trajectory tolerance, and the product edits in exactly
     the evaluations the reference did -- 40 of 100: grid points k * 0.01 (fp32) with "0.01" <= "{t:.2f}" <= "0.40", never "0.00"."""
-    from tests.test_oracle_golden import HOOKED_U, write_hooked_tables
+    from tests.test_oracle_golden import HOOKED_MID, HOOKED_U, write_hooked_tables
     from uspace_amd import _hip
     from uspace_amd.flow_matching import CNF
     from uspace_amd.libs import dissection
@@ -360,19 +360,26 @@ def test_cnf_hooked_uncond_solves_match_reference_trajectories(golden_dir, tmp_p
     net = net.cuda().eval()
     cnf = CNF(net)
     write_hooked_tables(str(tmp_path))
+    mid_dir = tmp_path / "mid"
+    mid_dir.mkdir()
+    write_hooked_tables(str(mid_dir), (5, 65, 64))
     planned, adds = [], []
     real_plan, real_add = dissection.plan_uspace_hook, _hip.add_broadcast
     monkeypatch.setattr(dissection, "plan_uspace_hook", lambda digit, kw: (lambda p: (planned.append((digit, None if p is None else os.path.basename(p.path))), p)[1])(real_plan(digit, kw)))
     monkeypatch.setattr(_hip, "add_broadcast", lambda *a, **k: (adds.append(1), real_add(*a, **k))[1])
     x0 = torch.from_numpy(zt["x"]).cuda()
     import json
-    for tag, kw in HOOKED_U:
+    for tag, kw in HOOKED_U + (("mid", HOOKED_MID),):
         planned.clear(), adds.clear()
-        x1 = cnf.decode(x0, None, dissect_task="uspace_uvit", dissect_name="write_attr", t_edit=0.4, write_path_root=str(tmp_path),
+        root = str(mid_dir if tag == "mid" else tmp_path)
+        x1 = cnf.decode(x0, None, dissect_task="uspace_uvit", dissect_name="write_attr", t_edit=0.4, write_path_root=root,
                         solver_kwargs=_solver_kwargs(solver_fix_step=0.01), **kw)
         assert cnf.last_stats.nfe == 100 and len(planned) == 100
         fired = [f for _d, f in planned if f is not None]
-        assert fired == json.loads(bytes(z[f"u_{tag}_files"]).decode()) and len(adds) == 40
+        # (the mid-block add happens inside the C call: 40 plans, no separate add launch; its fixture is documented semantics)
+        assert fired == [f"delta_{k / 100:.2f}.npy" for k in range(1, 41)] and len(adds) == (0 if tag == "mid" else 40)
+        if tag != "mid":
+            assert fired == json.loads(bytes(z[f"u_{tag}_files"]).decode())
         assert [d for d, f in planned if f is None][:1] == ["0.00"] and planned[30] == ("0.30", "delta_0.30.npy") and planned[41][1] is None
         r = rel_l2(x1.cpu().numpy(), z[f"u_{tag}_x1"])
         assert r < 5e-3, (tag, r)
@@ -411,7 +418,7 @@ def test_cnf_t2i_encode_then_decode_matches_reference_trajectories(golden_dir, m
 
 
 def test_cnf_euler50_L_t_matches_reference_trajectory(golden_dir):
-    """BASELINE configs[2] end to end at B = 2: U-ViT-L T2I (weights rebuilt from the seed), 50 Euler steps."""
+    """BASELINE configs[2] and configs[3] end to end at B = 2: U-ViT-L T2I and U-ViT-S-deep16 T2I (weights rebuilt from the seed), 50 Euler steps."""
     from uspace_amd.flow_matching_t2i import CNF
     from uspace_amd.tools.utils_uvit import get_nnet
     z = np.load(os.path.join(golden_dir, "hooked_traj.npz"))
@@ -426,3 +433,13 @@ def test_cnf_euler50_L_t_matches_reference_trajectory(golden_dir):
     assert cnf.last_stats.nfe == 50
     r = rel_l2(x1.cpu().numpy(), z["Lt_x1_euler50"])
     assert r < 5e-3, r
+    # BASELINE configs[3]: U-ViT-S-deep16 T2I, same latents and context
+    del cnf, net
+    torch.manual_seed(1234)
+    net_s = get_nnet("uvit_t2i", img_size=32, patch_size=2, in_chans=4, embed_dim=512, depth=16, num_heads=8, mlp_ratio=4, qkv_bias=False,
+                     mlp_time_embed=False, clip_dim=768, num_clip_token=77)
+    cnf_s = CNF(net_s.cuda().eval())
+    x1s = cnf_s.decode(torch.from_numpy(z["Lt_z"]).cuda(), torch.from_numpy(z["Lt_ctx"]).cuda(), dissect_name="none",
+                       solver_kwargs=_solver_kwargs(solver_fix_step=0.02))
+    rs = rel_l2(x1s.cpu().numpy(), z["St_x1_euler50"])
+    assert cnf_s.last_stats.nfe == 50 and rs < 5e-3, rs

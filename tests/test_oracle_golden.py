@@ -187,9 +187,12 @@ def hooked_delta_table(k, shape=(5, 4, 16, 16)):
     return (np.random.default_rng(4000 + k).standard_normal(shape) * 0.3).astype(np.float32)
 
 
-def write_hooked_tables(d):
+def write_hooked_tables(d, shape=(5, 4, 16, 16)):
     for k in range(0, 101):
-        np.save(os.path.join(d, f"delta_{k / 100:.2f}.npy"), hooked_delta_table(k))
+        np.save(os.path.join(d, f"delta_{k / 100:.2f}.npy"), hooked_delta_table(k, shape))
+
+
+HOOKED_MID = dict(edit_loc="mid", ith_attr="1_3", write_scale=6.0)          # token-shaped tables [5, 65, 64]: documented semantics
 
 
 HOOKED_U = (("tail", dict(edit_loc="tail", ith_attr=2, write_scale=1.0)), ("head", dict(edit_loc="head", ith_attr="1_3", write_scale=-4.0)))
@@ -222,6 +225,18 @@ def test_hooked_trajectories_follow_the_reference(golden_dir, monkeypatch):
             assert files == json.loads(bytes(z[f"u_{tag}_files"]).decode()) == [f"delta_{k / 100:.2f}.npy" for k in range(1, 41)]
             np.testing.assert_allclose(x1, z[f"u_{tag}_x1"], **tol)
             assert np.abs(z[f"u_{tag}_x1"] - z["u_plain_x1"]).max() > 0.02          # the edits moved the end state by 100x the tolerance
+        monkeypatch.undo()
+    # mid block (documented semantics: the reference's reader cannot take token-shaped tables; its should_edit() and file naming
+    # decided per evaluation in the generator): same 40 evaluations, token-shaped tables of their own
+    with tempfile.TemporaryDirectory() as d:
+        write_hooked_tables(d, (5, 65, 64))
+        files = []
+        real_load = np.load
+        monkeypatch.setattr(O.np, "load", lambda p, *a, **k: (files.append(os.path.basename(str(p))), real_load(p, *a, **k))[1])
+        kwargs = dict(dissect_task="uspace_uvit", dissect_name="write_attr", t_edit=0.4, write_path_root=d, **HOOKED_MID)
+        x1 = OO.solve(lambda t, y: O.uvit_forward(spec, sd, y, t, **kwargs), zt["x"], 0.0, 1.0, method="euler", step_size=0.01)
+        assert files == [f"delta_{k / 100:.2f}.npy" for k in range(1, 41)]
+        np.testing.assert_allclose(x1, z["u_mid_x1"], **tol)
         monkeypatch.undo()
     zt2, sd2 = _load(golden_dir, "tiny_t2i.npz")
     spec2 = O.UViTSpec(t2i=True, clip_dim=64, num_clip_token=77, **TINY)
