@@ -15,6 +15,7 @@
 //     are 16-byte (fp32) or 8-byte (bf16) vectors along N;
 //   * workgroup ids are remapped so that each XCD (private L2) owns a contiguous run of tiles.
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -400,18 +401,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
 #define LOAD_W(dst, base, ck)                                                                       \
     _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_)                                               \
         dst[j_] = *(const bf16x8*)((base) + w_lds + j_ * 16 * ROW_BYTES + (ck));
-#define LOAD_X(dst, base, ck) if (has_x) dst = *(const bf16x8*)((base) + x_lds + (ck));
+#define LOAD_X(dst, base, ck) if (X_ON) dst = *(const bf16x8*)((base) + x_lds + (ck));
 #define MMA(af, wf, mh, ilo, ihi)                                                                   \
     _Pragma("unroll") for (int i_ = (ilo); i_ < (ihi); ++i_)                                        \
         _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_)                                           \
             acc[(mh) * HM + i_][j_] =                                                               \
                 __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j_], af[i_], acc[(mh) * HM + i_][j_], 0, 0, 0);
 #define MMA_X(xf, wf)                                                                               \
-    if (XTRA && has_x) {                                                                            \
+    if (XTRA && X_ON) {                                                                             \
         _Pragma("unroll") for (int j_ = 0; j_ < XN; ++j_)                                           \
             xacc[j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pick_w<WM, XN>(wf, wm, j_), xf, xacc[j_], 0, 0, 0); \
     }
 
+    // does this workgroup own a strip?  A run-time fact here; the two-stage K loop below is compiled twice (X_ON a constant in each copy)
+    const bool X_ON = has_x;
     const int nk = NST > 2 ? g.nk_split : g.K / BK;
     // LayerNorm folding: thread t fetches the per-row values of tile row t (main rows, then the 16 strip rows) right
     // behind the first LDS-DMA stages -- their latency overlaps the first tile's -- and parks them in LDS after the barrier
@@ -711,11 +714,28 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         static_assert(NST <= 8, "tail steps are written out up to NST = 8");
         KTILE_R(kt, buf, 0, false, false, 0)
     } else {
-        // steady state is branch-free; the last two K tiles are peeled (no further prefetch / barrier)
-        int kt = 0;
-        for (; kt + 2 < nk; ++kt) KTILE(kt, true, true)
-        if (kt + 1 < nk) { KTILE(kt, true, false) ++kt; }
-        KTILE(kt, false, false)
+        // steady state is branch-free; the last two K tiles are peeled (no further prefetch / barrier).  Two copies: 15 of 16 workgroups
+        // of a launch with remainder strips own none, and their loop has no strip branches at all
+        auto kloop = [&](auto xon) __attribute__((always_inline)) {
+            constexpr bool X_ON = decltype(xon)::value;
+            int kt = 0;
+            for (; kt + 2 < nk; ++kt) KTILE(kt, true, true)
+            if (kt + 1 < nk) { KTILE(kt, true, false) ++kt; }
+            KTILE(kt, false, false)
+        };
+        if constexpr (XTRA && (FLAGS & USPACE_EPI_RESIDUAL) == 0) {
+            if (has_x) kloop(std::true_type{});
+            else kloop(std::false_type{});
+        } else if constexpr (XTRA) {
+            // (the residual forms keep their accumulator-initialising loads in flight into the loop and have no register to spare for a
+            // second copy's live ranges: one loop with the run-time test)
+            int kt = 0;
+            for (; kt + 2 < nk; ++kt) KTILE(kt, true, true)
+            if (kt + 1 < nk) { KTILE(kt, true, false) ++kt; }
+            KTILE(kt, false, false)
+        } else {
+            kloop(std::false_type{});
+        }
     }
 #undef KTILE_R
 #undef KTILE
