@@ -274,7 +274,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
     }
     const int wave_lds_off = wave * 8 * ROW_BYTES;  // this wave's 8 rows inside an issue
 
-    const int n_slab = g.n_slab, k1_log2 = g.k1_log2;
+    // (a LayerNorm consumer reads ONE centred copy: K is a single slab there, checked on the host -- the slab test leaves its K loop)
+    const int n_slab = (FLAGS & USPACE_EPI_LN_IN) ? 1 : g.n_slab, k1_log2 = g.k1_log2;
     const long lda_l = g.lda;
     auto a_base = [&](int k0) -> const char* {
         // slab s covers K range [s*K1, (s+1)*K1): second operand pointer for the long skip (A2), or the same
@@ -298,7 +299,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         else
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (US_LDS void*)lds, 16, voff, 0, 0, 0);
     };
-    auto stage_a = [&](int kt, int buf) {
+    // (do_x: stage the strip's rows as well -- has_x by default; the strip-free copy of the K loop passes a constant false)
+    auto stage_a = [&](int kt, int buf, bool do_x) {
         const int k0 = (kt + kt0) * BK;
         char* base = smem + buf * STAGE_BYTES;
         const char* abase = a_base(k0);
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
 #pragma unroll
         for (int i = 0; i < ISSUES_A; ++i) dma16(abase, rs, a_off[i], base + i * ROWS_PER_ISSUE * ROW_BYTES + wave_lds_off);
         if constexpr (XTRA) {
-            if (has_x && wave < 2) dma16(abase, rs, x_off, base + TILE_A_BYTES + TILE_W_BYTES + wave_lds_off);
+            if (do_x && wave < 2) dma16(abase, rs, x_off, base + TILE_A_BYTES + TILE_W_BYTES + wave_lds_off);
         }
     };
     auto stage_w = [&](int kt, int buf) {
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         // tile queues behind them in the texture path (fc1 of U-ViT-S at 4 x 257 rows: 11.4 us against 9.8)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            stage_a(t, t);
+            stage_a(t, t, has_x);
             stage_w(t, t);
         }
         // (strip owners' first two waves have one more instruction per stage in flight: their count is a lower bound, they wait for
@@ -460,13 +462,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int t = 2; t < NST; ++t) {
-            stage_a(t, t);
+            stage_a(t, t, has_x);
             stage_w(t, t);
         }
     } else {
-        stage_a(0, 0);
+        stage_a(0, 0, has_x);
         stage_w(0, 0);
-        if (nk > 1) stage_a(1, 1);
+        if (nk > 1) stage_a(1, 1, has_x);
         if constexpr (ROWV) fetch_rowv();
         if constexpr (EARLY_EPI) load_epi_consts();
         __syncthreads();
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         __builtin_amdgcn_sched_barrier(0);                                                         \
         if (MORE) {                                                                                \
             __syncthreads(); /* tile kt+1 landed for everyone; buffer kt&1 is free */              \
-            if (MORE2) stage_a(kt + 2, kt & 1);                                                    \
+            if (MORE2) stage_a(kt + 2, kt & 1, X_ON);                                                  \
             const char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;                                 \
             LOAD_A(af0, nxt, 0, c_k0)                                                              \
             LOAD_W(wf0, nxt, c_k0)                                                                 \
@@ -583,7 +585,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
             wait_vm<WAITN>();                                                                      \
             __builtin_amdgcn_s_barrier(); /* tile kt+1 landed for everyone; buffer buf is free */  \
             if (REFILL) {                                                                          \
-                stage_a(kt + NST, buf);                                                            \
+                stage_a(kt + NST, buf, has_x);                                                          \
                 stage_w(kt + NST, buf);                                                            \
             }                                                                                      \
             const char* nxt = smem + (nbuf) * STAGE_BYTES;                                         \
@@ -634,7 +636,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
             __builtin_amdgcn_sched_barrier(0);                                                     \
             /* the refill has the ring's slack: its address arithmetic runs beside the MFMAs, behind the fragment reads */ \
             if (REFILL) {                                                                          \
-                stage_a(kt + NST, buf);                                                            \
+                stage_a(kt + NST, buf, has_x);                                                          \
                 stage_w(kt + NST, buf);                                                            \
             }                                                                                      \
             T_MMA(P)                                                                               \
@@ -653,7 +655,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
             __builtin_amdgcn_s_barrier();                                                          \
             T_LOAD(Q, smem + nb_ * STAGE_BYTES)                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                     \
-            stage_a(kt + NST, BUFC);                                                               \
+            stage_a(kt + NST, BUFC, has_x);                                                             \
             stage_w(kt + NST, BUFC);                                                               \
             T_MMA(P)                                                                               \
             __builtin_amdgcn_sched_barrier(0);                                                     \
@@ -1399,6 +1401,7 @@ extern "C" int uspace_gemm_bf16_ext(const uint16_t* A, int lda, const uint16_t* 
         if (!(epi_flags & USPACE_EPI_CEN_OUT) || !g.row_add || !g.col_add) return USPACE_ERR_ARG;
     }
     if (epi_flags & USPACE_EPI_LN_IN) {
+        if (g.n_slab != 1) return USPACE_ERR_ARG;
         if (!g.part_in || g.np_in <= 0 || g.np_in > 8 || !g.colsum || g.inv_d <= 0.f || (g.c_out && !g.row_c)) return USPACE_ERR_ARG;
     }
     g.wide = wide_ok(g, epi_flags);
