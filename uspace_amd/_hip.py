@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libuspace_hip.so")
+# (USPACE_HIP_LIB: another build of the same ABI, for A/B measurements of whole solves on one box -- tools/lab/)
+LIB_PATH = os.environ.get("USPACE_HIP_LIB") or os.path.join(_HERE, "libuspace_hip.so")
 
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_OUT_BF16 = 1, 2, 4, 8, 16
 EPI_CEN_OUT, EPI_LN_IN, EPI_RANK1 = 32, 64, 128          # uspace_gemm_bf16_ext only (LayerNorm folded through the GEMMs)
