@@ -29,6 +29,12 @@
 #ifndef USPACE_ATT_W4
 #define USPACE_ATT_W4 0
 #endif
+#if defined(USPACE_ATT_W6) && !USPACE_LAB
+#error "USPACE_ATT_W6 is a lab switch: build with tools/lab/build_variant.sh (-DUSPACE_LAB=1)"
+#endif
+#ifndef USPACE_ATT_W6
+#define USPACE_ATT_W6 0
+#endif
 
 namespace {
 
@@ -67,7 +73,7 @@ __device__ __forceinline__ uint2 lds_read_tr16(const char* p) {
 // W4: four waves per SIMD -- two 8-wave workgroups per CU (L <= 272: 70 KB of LDS each) at <= 128 registers; the K fragments are then
 // fetched two key tiles ahead instead of four (twice the waves cover the LDS latency).
 template <int NT, int LC, bool SCALED, int NW, bool CAUSAL = false, int QS = 1, int HPW = 1, bool W4 = false>
-__global__ __launch_bounds__(64 * NW, W4 ? 4 : 2) void attention_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(64 * NW, NW == 6 ? 3 : (W4 ? 4 : 2)) void attention_kernel(const bf16_t* __restrict__ qkv,
                                                            const float* __restrict__ key_scale,
                                                            bf16_t* __restrict__ out, int L_rt, int H, int BH) {
     const int L = LC > 0 ? LC : L_rt;
@@ -424,6 +430,16 @@ int launch_attn2(const bf16_t* qkv, const float* ks, bf16_t* out, int B, int L, 
             return USPACE_OK;
         }
     }
+#if USPACE_ATT_W6
+    if constexpr (!SCALED && NW == 4 && LC > 0) {     // lab: six waves per workgroup, two workgroups per CU = three waves per SIMD
+        static std::atomic<uint64_t> lds_ok_w6{0};
+        US_TRY(us_opt_in_lds((const void*)attention_kernel<NT, LC, false, 6>, 160 * 1024, lds_ok_w6));
+        hipLaunchKernelGGL((attention_kernel<NT, LC, false, 6>), dim3(B * H), dim3(384), lds, s, qkv, ks, out, L, H, B * H);
+        us_rec_end(rec, s);
+        US_CHECK_LAUNCH();
+        return USPACE_OK;
+    }
+#endif
 #if USPACE_ATT_W4
     if constexpr (!SCALED && NW == 4 && LC > 0) {
         static std::atomic<uint64_t> lds_ok_w4{0};
