@@ -38,6 +38,7 @@
 
 namespace {
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 constexpr int DH = 64;
 constexpr int KROW_BYTES = 128;
 
@@ -265,21 +266,42 @@ __global__ __launch_bounds__(64 * NW, NW == 6 ? 3 : (W4 ? 4 : 2)) void attention
                 for (int r = 0; r < 4; ++r) s[t][r] = (t * 16 + fq * 4 + r) <= (q0 + fr) ? s[t][r] : -INFINITY;
         }
         // ---- row max
-        float mx = s[0][0];
+        // four independent chains (a single one is NT dependent v_max3_f32), then the 16-lane rows: v_permlane16_swap / v_permlane32_swap
+        // on two copies of the value leave rows (0, 0, 2, 2) | (1, 1, 3, 3) resp. halves (lo, lo) | (hi, hi) -- one VALU instruction where
+        // __shfl_xor is a trip through the LDS crossbar
+        float mq[4] = {s[0][0], s[0][0], s[0][0], s[0][0]};
 #pragma unroll
         for (int t = 0; t < NT; ++t) {   // two v_max3_f32 per tile (nested form the backend fuses)
-            mx = fmaxf(fmaxf(mx, s[t][0]), s[t][1]);
-            mx = fmaxf(fmaxf(mx, s[t][2]), s[t][3]);
+            mq[(2 * t) & 3] = fmaxf(fmaxf(mq[(2 * t) & 3], s[t][0]), s[t][1]);
+            mq[(2 * t + 1) & 3] = fmaxf(fmaxf(mq[(2 * t + 1) & 3], s[t][2]), s[t][3]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float mx = fmaxf(fmaxf(mq[0], mq[1]), fmaxf(mq[2], mq[3]));
+        {
+            const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+            const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+        }
         const float mc = mx * c_exp;
         // p = 2^(s*c - mx*c), one 32-key step (two key tiles) at a time
         auto exp_step = [&](int u) {
 #pragma unroll
-            for (int tt = 2 * u; tt < 2 * u + 2 && tt < NT; ++tt)
+            for (int tt = 2 * u; tt < 2 * u + 2 && tt < NT; ++tt) {
+                if constexpr (LC > 0) {
+                    // two values per v_pk_fma_f32: same rounding, 32 instructions fewer per query tile (L = 334: -1.5 %, L = 257: neutral;
+                    // the generic-length forms keep the scalar fma: the register pairs cost their SCALED instantiations 12 bytes of scratch)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s[tt][r] = __builtin_amdgcn_exp2f(fmaf(s[tt][r], c_exp, -mc));
+                    for (int r = 0; r < 4; r += 2) {
+                        f32x2 a = {s[tt][r], s[tt][r + 1]};
+                        a = __builtin_elementwise_fma(a, (f32x2){c_exp, c_exp}, (f32x2){-mc, -mc});
+                        s[tt][r] = __builtin_amdgcn_exp2f(a[0]);
+                        s[tt][r + 1] = __builtin_amdgcn_exp2f(a[1]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[tt][r] = __builtin_amdgcn_exp2f(fmaf(s[tt][r], c_exp, -mc));
+                }
+            }
         };
         // ---- O^T = V^T . P^T over 32-key steps; k-slot (fq, e): e<4 -> tile 2u key 4fq+e, e>=4 -> tile 2u+1.
         //      Software pipeline per step u: V^T fragments of step u+1 are requested, the MFMAs of step u are issued,
