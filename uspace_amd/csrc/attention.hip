@@ -36,6 +36,29 @@
 #define USPACE_ATT_W6 0
 #endif
 
+// lab switch: cycle stamps (s_memtime) of wave phases of two workgroups of the L = 257 launch, read back with uspace_lab_att_trace()
+// (tools/lab/att_trace.py).  Every stamp waits for the wave's outstanding LDS reads (s_memtime returns through lgkmcnt): a coarse picture.
+#if defined(USPACE_ATT_TRACE) && !USPACE_LAB
+#error "USPACE_ATT_TRACE is a lab switch: build with tools/lab/build_variant.sh (-DUSPACE_LAB=1)"
+#endif
+#ifndef USPACE_ATT_TRACE
+#define USPACE_ATT_TRACE 0
+#endif
+#if USPACE_ATT_TRACE
+__device__ unsigned long long g_att_trace[2 * 4 * 64];
+#define ATT_STAMP(slot)                                                                                   \
+    if constexpr (NW == 4 && LC == 257 && QS == 1 && HPW == 1 && !SCALED) {                               \
+        if (tr_blk >= 0) {                                                                                \
+            unsigned long long t_;                                                                        \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+            const int sl_ = (slot);                                                                       \
+            if (lane == 0 && sl_ < 64) g_att_trace[(tr_blk * 4 + wave) * 64 + sl_] = t_;                  \
+        }                                                                                                 \
+    }
+#else
+#define ATT_STAMP(slot)
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -89,6 +112,11 @@ __global__ __launch_bounds__(64 * NW, NW == 6 ? 3 : (W4 ? 4 : 2)) void attention
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if USPACE_ATT_TRACE
+    const int tr_blk = blockIdx.x == 0 ? 0 : (blockIdx.x == 700 ? 1 : -1);
+    int tr_slot = 0;
+#endif
+    ATT_STAMP(tr_slot++)
     static_assert(HPW == 1 || (QS == 1 && !SCALED && !CAUSAL), "several heads per workgroup: the plain full-batch form only");
     int bh = QS > 1 ? blockIdx.x / QS : blockIdx.x;
     const int qwave = QS > 1 ? (int)(blockIdx.x % QS) * NW + wave : wave;   // this wave's first query tile
@@ -163,6 +191,7 @@ __global__ __launch_bounds__(64 * NW, NW == 6 ? 3 : (W4 ? 4 : 2)) void attention
     // become inline asm; and the prize is small -- staging is HBM-bound (K + V of all heads at 6.5 TB/s), K first moves no byte and
     // could cover only one query tile's Q.K^T phase per wave (~0.5 us of 39).
     __syncthreads();   // (drains the LDS-DMA queue) K, V^T, key scales visible
+    ATT_STAMP(tr_slot++)
 
 #pragma unroll 1
     for (int hh = 0; hh < HPW; ++hh) {
@@ -249,6 +278,7 @@ __global__ __launch_bounds__(64 * NW, NW == 6 ? 3 : (W4 ? 4 : 2)) void attention
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        ATT_STAMP(tr_slot++)   // Q.K^T issued and waited for
         // ---- mask: only the last valid tile can hold keys >= L; tiles after it are all invalid
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -283,6 +313,7 @@ __global__ __launch_bounds__(64 * NW, NW == 6 ? 3 : (W4 ? 4 : 2)) void attention
             mx = fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
         }
         const float mc = mx * c_exp;
+        ATT_STAMP(tr_slot++)   // row maximum known
         // p = 2^(s*c - mx*c), one 32-key step (two key tiles) at a time
         auto exp_step = [&](int u) {
 #pragma unroll
@@ -362,14 +393,15 @@ __global__ __launch_bounds__(64 * NW, NW == 6 ? 3 : (W4 ? 4 : 2)) void attention
                 const bool more = (u + 1 < NP) && (2 * (u + 1) <= t_last);
                 if (more) load_v(u + 1, vb[(u + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
+        #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb[u & 1][dt].v, pb[u & 1].v, o[dt], 0, 0, 0);
                 osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, SCALED ? pu[u & 1].v : pb[u & 1].v, osum, 0, 0, 0);
-                if (more) make_p(u + 1);
+                        if (more) make_p(u + 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        ATT_STAMP(tr_slot++)   // P.V done
         const float inv = 1.0f / osum[0];
         // ---- store: lane holds query q0+fr, head dims dt*16 + 4*fq + {0..3}
         const int q = q0 + fr;
@@ -385,6 +417,7 @@ __global__ __launch_bounds__(64 * NW, NW == 6 ? 3 : (W4 ? 4 : 2)) void attention
         }
         qf[0] = qn[0];
         qf[1] = qn[1];
+        ATT_STAMP(tr_slot++)   // tile stored, next Q fragment in
     }
     if constexpr (HPW > 1) {
         if (!pf_on) break;
@@ -496,6 +529,12 @@ int launch_attn_causal(const bf16_t* qkv, bf16_t* out, int B, int L, int H, hipS
 }
 
 }  // namespace
+
+#if USPACE_ATT_TRACE
+extern "C" __attribute__((visibility("default"))) int uspace_lab_att_trace(unsigned long long* dst) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_att_trace), sizeof(g_att_trace)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int uspace_attention_causal_bf16(const uint16_t* qkv, uint16_t* out, int B, int L, int H, uspace_stream_t stream) {
     if (!qkv || !out || B <= 0 || L <= 0 || H <= 0) return USPACE_ERR_ARG;
