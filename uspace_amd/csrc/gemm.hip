@@ -71,7 +71,7 @@ constexpr int BK = 64;           // bf16 elements per K step (128 B per LDS row)
 #if !USPACE_LAB
 #if defined(USPACE_ABLATE_NOSTORE) || defined(USPACE_ABLATE_NOEPI) || defined(USPACE_ABLATE_NOGELU) || defined(USPACE_DMA_FLAT) || \
     defined(USPACE_RING_PREFETCH_ALL) || defined(USPACE_TINY_UNROLL) || defined(USPACE_EARLY_BARRIER) || defined(USPACE_TALL_COST) || defined(USPACE_CHAIN) || \
-    defined(USPACE_CHAIN_ABL) || defined(USPACE_CHAIN_DMA8) || defined(USPACE_CHAIN_SPLIT) || defined(USPACE_CHAIN_BODY)
+    defined(USPACE_CHAIN_ABL) || defined(USPACE_CHAIN_DMA8) || defined(USPACE_CHAIN_SPLIT) || defined(USPACE_CHAIN_BODY) || defined(USPACE_FULL_LINES)
 #error "measurement switches need -DUSPACE_LAB=1 (tools/lab/build_variant.sh); the product build takes none"
 #endif
 #define USPACE_ABLATE_NOSTORE 0
@@ -99,6 +99,9 @@ constexpr int BK = 64;           // bf16 elements per K step (128 B per LDS row)
 #endif
 #ifndef USPACE_TINY_UNROLL
 #define USPACE_TINY_UNROLL 1
+#endif
+#ifndef USPACE_FULL_LINES
+#define USPACE_FULL_LINES 0      // bit mask: 1 = bf16 outputs, 2 = fp32 output of interior tiles as 8 rows x 128 B per store instruction (A/B measurements)
 #endif
 #ifndef USPACE_CHAIN
 #define USPACE_CHAIN 0           // 1: multi-round store-only launches of 256x256 tiles take the chain form (gemm_chain.h)
@@ -143,6 +146,19 @@ __device__ __forceinline__ uint4 widen_pair(uint2 a, uint2 b) {
     const auto ry = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
     return make_uint4(rx[0], ry[0], rx[1], ry[1]);
 }
+
+// Two 16-byte vectors per lane, each laid out as 16 rows (lane % 16) x 64 contiguous bytes (the left and the right half of 128-byte
+// row segments) -> lo: rows 0-7 with all 128 bytes (lanes 8-15 of each 16-lane group take the right half of row lane - 8),
+// hi: rows 8-15.  One DPP move (row_ror:8, half of the banks) per dword: a store instruction then writes 8 whole cache lines.
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+__device__ __forceinline__ void line_pair(const u32x4& l, const u32x4& r, u32x4& lo, u32x4& hi) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        lo[c] = (uint32_t)__builtin_amdgcn_update_dpp((int)l[c], (int)r[c], 0x128, 0xf, 0xc, false);
+        hi[c] = (uint32_t)__builtin_amdgcn_update_dpp((int)r[c], (int)l[c], 0x128, 0xf, 0x3, false);
+    }
+}
+__device__ __forceinline__ u32x4 as_u32x4(const uint4& v) { return (u32x4){v.x, v.y, v.z, v.w}; }
 
 // byte offset inside a [rows][64] bf16 LDS tile of 16-B chunk `c` of row `r` (swizzled)
 __device__ __forceinline__ int lds_off(int r, int c) { return r * ROW_BYTES + ((c ^ ((r >> 1) & 7)) << 4); }
@@ -855,6 +871,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         return;
     }
 #endif
+    constexpr bool FL_BF = (USPACE_FULL_LINES & 1) != 0 && TN == 4, FL_F32 = (USPACE_FULL_LINES & 2) != 0 && TN == 4;
     if (interior && g.wide) {
         const int nw = n0 + wn * (BN / WN) + (fq & 1) * 16 + (fq >> 1) * 8;   // this lane's column in a widened pair (+ 32 per pair)
 #pragma unroll
@@ -872,7 +889,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
             f32x4 s1v = {0.f, 0.f, 0.f, 0.f}, s2v = {0.f, 0.f, 0.f, 0.f};   // CEN: the row's sums as packed vector accumulators
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                if constexpr (FLAGS & USPACE_EPI_OUT_F32) *(f32x4*)(out_f32 + (size_t)m * g.ld_f32 + n0 + wn * (BN / WN) + j * 16 + fq * 4) = v[j];
+                if constexpr ((FLAGS & USPACE_EPI_OUT_F32) != 0 && !FL_F32) *(f32x4*)(out_f32 + (size_t)m * g.ld_f32 + n0 + wn * (BN / WN) + j * 16 + fq * 4) = v[j];
+                if constexpr ((FLAGS & USPACE_EPI_OUT_F32) != 0 && FL_F32) {
+                    if (j & 1) {
+                        u32x4 lo, hi;
+                        line_pair(__builtin_bit_cast(u32x4, v[j - 1]), __builtin_bit_cast(u32x4, v[j]), lo, hi);
+                        float* po = out_f32 + (size_t)(m0 + wm * (BM / WM) + i * 16 + (fr & 7)) * g.ld_f32 + n0 + wn * (BN / WN) + (j - 1 + (fr >> 3)) * 16 + fq * 4;
+                        *(u32x4*)po = lo;
+                        *(u32x4*)(po + 8 * (size_t)g.ld_f32) = hi;
+                    }
+                }
                 if constexpr (FLAGS & USPACE_EPI_OUT_BF16) {
                     pk[j].x = pack_bf2(v[j][0], v[j][1]);
                     pk[j].y = pack_bf2(v[j][2], v[j][3]);
@@ -890,10 +916,28 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
                 ps2 = (s2v[0] + s2v[1]) + (s2v[2] + s2v[3]);
             }
 #if !USPACE_ABLATE_NOSTORE
+            if constexpr (FL_BF) {
+                // whole 128-byte lines: rows 0-7 of the sub-tile row in one store instruction, rows 8-15 in the next
+                const size_t mr = (size_t)(m0 + wm * (BM / WM) + i * 16 + (fr & 7));
+                const int nl = n0 + wn * (BN / WN) + (fr >> 3) * 32 + (fq & 1) * 16 + (fq >> 1) * 8;
+                if constexpr (FLAGS & USPACE_EPI_OUT_BF16) {
+                    u32x4 lo, hi;
+                    line_pair(as_u32x4(widen_pair(pk[0], pk[1])), as_u32x4(widen_pair(pk[2], pk[3])), lo, hi);
+                    *(u32x4*)(g.out_bf16 + mr * g.ld_bf16 + nl) = lo;
+                    *(u32x4*)(g.out_bf16 + (mr + 8) * g.ld_bf16 + nl) = hi;
+                }
+                if constexpr (CEN) {
+                    u32x4 lo, hi;
+                    line_pair(as_u32x4(widen_pair(pc[0], pc[1])), as_u32x4(widen_pair(pc[2], pc[3])), lo, hi);
+                    *(u32x4*)(g.out_cen + mr * g.ld_cen + nl) = lo;
+                    *(u32x4*)(g.out_cen + (mr + 8) * g.ld_cen + nl) = hi;
+                }
+            } else {
 #pragma unroll
-            for (int j = 0; j < TN; j += 2) {
-                if constexpr (FLAGS & USPACE_EPI_OUT_BF16) *(uint4*)(g.out_bf16 + (size_t)m * g.ld_bf16 + nw + j * 16) = widen_pair(pk[j], pk[j + 1]);
-                if constexpr (CEN) *(uint4*)(g.out_cen + (size_t)m * g.ld_cen + nw + j * 16) = widen_pair(pc[j], pc[j + 1]);
+                for (int j = 0; j < TN; j += 2) {
+                    if constexpr (FLAGS & USPACE_EPI_OUT_BF16) *(uint4*)(g.out_bf16 + (size_t)m * g.ld_bf16 + nw + j * 16) = widen_pair(pk[j], pk[j + 1]);
+                    if constexpr (CEN) *(uint4*)(g.out_cen + (size_t)m * g.ld_cen + nw + j * 16) = widen_pair(pc[j], pc[j + 1]);
+                }
             }
 #endif
             row_end(m, true, wm * (BM / WM) + i * 16 + fr, wn);   // main rows: wave (wm, wn) fills slot wn of its rows
