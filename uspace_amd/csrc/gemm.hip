@@ -71,7 +71,7 @@ constexpr int BK = 64;           // bf16 elements per K step (128 B per LDS row)
 #if !USPACE_LAB
 #if defined(USPACE_ABLATE_NOSTORE) || defined(USPACE_ABLATE_NOEPI) || defined(USPACE_ABLATE_NOGELU) || defined(USPACE_DMA_FLAT) || \
     defined(USPACE_RING_PREFETCH_ALL) || defined(USPACE_TINY_UNROLL) || defined(USPACE_EARLY_BARRIER) || defined(USPACE_TALL_COST) || defined(USPACE_CHAIN) || \
-    defined(USPACE_CHAIN_ABL) || defined(USPACE_CHAIN_DMA8) || defined(USPACE_CHAIN_SPLIT) || defined(USPACE_CHAIN_BODY) || defined(USPACE_FULL_LINES)
+    defined(USPACE_CHAIN_ABL) || defined(USPACE_CHAIN_DMA8) || defined(USPACE_CHAIN_SPLIT) || defined(USPACE_CHAIN_BODY) || defined(USPACE_FULL_LINES) || defined(USPACE_KTRACE)
 #error "measurement switches need -DUSPACE_LAB=1 (tools/lab/build_variant.sh); the product build takes none"
 #endif
 #define USPACE_ABLATE_NOSTORE 0
@@ -100,11 +100,37 @@ constexpr int BK = 64;           // bf16 elements per K step (128 B per LDS row)
 #ifndef USPACE_TINY_UNROLL
 #define USPACE_TINY_UNROLL 1
 #endif
+#ifndef USPACE_KTRACE
+#define USPACE_KTRACE 0          // 1: cycle stamps (s_memtime) around the K loop's barriers of two workgroups, read with uspace_lab_gemm_trace (tools/lab/gemm_trace.py)
+#endif
 #ifndef USPACE_FULL_LINES
 #define USPACE_FULL_LINES 0      // bit mask: 1 = bf16 outputs, 2 = fp32 output of interior tiles as 8 rows x 128 B per store instruction (A/B measurements)
 #endif
 #ifndef USPACE_CHAIN
 #define USPACE_CHAIN 0           // 1: multi-round store-only launches of 256x256 tiles take the chain form (gemm_chain.h)
+#endif
+#if USPACE_KTRACE
+// 2 workgroups x 8 waves x 64 stamps (low 32 bits of s_memtime), kept in one VGPR per wave (lane = slot) until the kernel's end
+__device__ uint32_t g_gemm_trace[2 * 8 * 64];
+#define K_STAMP(slot)                                                                      \
+    if (ktr_on) {                                                                          \
+        unsigned long long t_;                                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
+        ktr = lane == ((slot) & 63) ? (uint32_t)t_ : ktr;                                  \
+    }
+// phase stamps inside a K tile: s_memtime without a wait (a wait would serialise the fragment prefetch); the three values are parked in
+// SGPRs and copied into lanes 32 + 3 (kt - 4) + i at the tile's barrier stamp, K tiles 4..11.  (The outstanding SMEM result shifts the
+// compiler's counted lgkmcnt waits by one: a fragment may be consumed a few cycles early -- results of this build are not to be trusted.)
+#define K_PHASE(i) asm volatile("s_memtime %0" : "=s"(ktph[i]));
+#define K_PHASE_FLUSH(kt)                                                                  \
+    if (ktr_on && (kt) >= 4 && (kt) < 12) {                                                \
+        _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_)                                   \
+            ktr = lane == 32 + 3 * ((kt) - 4) + i_ ? (uint32_t)ktph[i_] : ktr;             \
+    }
+#else
+#define K_STAMP(slot)
+#define K_PHASE(i)
+#define K_PHASE_FLUSH(kt)
 #endif
 constexpr int ROW_BYTES = 128;
 
@@ -222,6 +248,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN;
     const int wn = wave % WN;
+#if USPACE_KTRACE
+    const int ktr_blk = blockIdx.x == 10 ? 0 : (blockIdx.x == 600 ? 1 : -1);
+    const bool ktr_on = ktr_blk >= 0 && NST == 2 && BM == 256 && BN == 256;
+    uint32_t ktr = 0;
+    unsigned long long ktph[3] = {0, 0, 0};
+    K_STAMP(0)
+#endif
 
     // ---- XCD-aware tile id.  Block b runs on XCD b%8 (observed; speed only).  When the grid splits into
     //      super-tiles of 8 x 4 tiles (one round of an XCD's 32 CUs) each XCD walks whole super-tiles, so
@@ -488,6 +521,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         if constexpr (ROWV) fetch_rowv();
         if constexpr (EARLY_EPI) load_epi_consts();
         __syncthreads();
+        K_STAMP(1)
     }
     if constexpr (ROWV) {
         if (tid < BM + 16) {
@@ -537,6 +571,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         __builtin_amdgcn_sched_barrier(0);                                                         \
         MMA(af0, wf0, 0, 1, HM)                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                         \
+        K_PHASE(0)                                                                                 \
         MMA(af1, wf0, 1, 0, 1)                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         LOAD_A(af0, cur, 0, c_k1)                                                                  \
@@ -545,6 +580,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         __builtin_amdgcn_sched_barrier(0);                                                         \
         MMA(af1, wf0, 1, 1, HM)                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                         \
+        K_PHASE(1)                                                                                 \
         MMA(af0, wf1, 0, 0, 1)                                                                     \
         MMA_X(xf1, wf1)                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                         \
@@ -552,10 +588,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         __builtin_amdgcn_sched_barrier(0);                                                         \
         MMA(af0, wf1, 0, 1, HM)                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                         \
+        K_PHASE(2)                                                                                 \
         if constexpr (!EARLYB) { MMA(af1, wf1, 1, 0, HM / 2) }                                     \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         if (MORE) {                                                                                \
+            K_STAMP(2 + 2 * (kt))                                                                  \
+            K_PHASE_FLUSH(kt)                                                                      \
             __syncthreads(); /* tile kt+1 landed for everyone; buffer kt&1 is free */              \
+            K_STAMP(3 + 2 * (kt))                                                                  \
             if (MORE2) stage_a(kt + 2, kt & 1, X_ON);                                                  \
             const char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;                                 \
             LOAD_A(af0, nxt, 0, c_k0)                                                              \
@@ -763,6 +803,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
 #undef MMA
 #undef MMA_X
 
+    K_STAMP(62)
     // ---- epilogue: lane holds, for sub-tile (i,j), row m = ..+fr and columns n = ..+4*fq+{0,1,2,3}
     if constexpr (!EARLY_EPI) load_epi_consts();
     float ps1 = 0.f, ps2 = 0.f;   // producer: running partial sums of the row being emitted
@@ -998,6 +1039,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
             po[1] = bq;
         }
     }
+#if USPACE_KTRACE
+    K_STAMP(63)
+    if (ktr_on && wave < 8) g_gemm_trace[(ktr_blk * 8 + wave) * 64 + lane] = ktr;
+#endif
 }
 
 // Tiling plan: how many BM-row tile rows get their own workgroups, the remaining rows being cut into n_strip strips of 16
@@ -1451,6 +1496,12 @@ extern "C" int uspace_gemm_bf16_ext(const uint16_t* A, int lda, const uint16_t* 
     g.wide = wide_ok(g, epi_flags);
     return dispatch_flags(g, epi_flags, (hipStream_t)stream);
 }
+
+#if USPACE_KTRACE
+extern "C" __attribute__((visibility("default"))) int uspace_lab_gemm_trace(uint32_t* dst) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gemm_trace), sizeof(g_gemm_trace)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int uspace_gemm_bf16(const uint16_t* A, int lda, const uint16_t* A2, int lda2, int K1,
                                 const uint16_t* W, int ldw, int M, int N, int K, int epi_flags,
