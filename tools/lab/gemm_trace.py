@@ -40,7 +40,13 @@ for blk, name in enumerate(("workgroup 10", "workgroup 600")):
         wait = [int(d(after[w], before[w])) for w in range(8)]
         wait_tot += wait; work_tot += work
         print(f"  K tile {kt:2d}: work {work} | barrier wait {wait}")
-    if r[:, 32:56].any():
+    if len(sys.argv) > 4 and sys.argv[4] == "vm":
+        print("  wait for the wave's own LDS-DMA in front of the barrier | barrier after that:")
+        for kt in range(nk - 1):
+            vm = [int(d(r[w, 32 + kt], r[w, 2 + 2 * kt])) for w in range(8)]
+            ba = [int(d(r[w, 3 + 2 * kt], r[w, 32 + kt])) for w in range(8)]
+            print(f"    K tile {kt:2d}: vmcnt wait {vm} | barrier {ba}")
+    elif r[:, 32:56].any():
         print("  phases of K tiles 4..11 (after barrier -> 8 left-over MFMAs + 16 of phase 0 | phase 1 (16) | phase 2 (16) | phase 3 first 8 -> at barrier | wait):")
         for kt in range(4, min(12, nk - 1)):
             for w in (0, 4, 1, 5):

@@ -127,10 +127,23 @@ __device__ uint32_t g_gemm_trace[2 * 8 * 64];
         _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_)                                   \
             ktr = lane == 32 + 3 * ((kt) - 4) + i_ ? (uint32_t)ktph[i_] : ktr;             \
     }
+// USPACE_KTRACE == 2: instead of the phase stamps, the wait for this wave's own LDS-DMA in front of the barrier is stamped separately (slot 32 + kt)
+#if USPACE_KTRACE == 2
+#undef K_PHASE
+#undef K_PHASE_FLUSH
+#define K_PHASE(i)
+#define K_PHASE_FLUSH(kt)
+#define K_VMWAIT(kt)                                                                       \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
+    K_STAMP(32 + (kt))
+#else
+#define K_VMWAIT(kt)
+#endif
 #else
 #define K_STAMP(slot)
 #define K_PHASE(i)
 #define K_PHASE_FLUSH(kt)
+#define K_VMWAIT(kt)
 #endif
 constexpr int ROW_BYTES = 128;
 
@@ -594,6 +607,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         if (MORE) {                                                                                \
             K_STAMP(2 + 2 * (kt))                                                                  \
             K_PHASE_FLUSH(kt)                                                                      \
+            K_VMWAIT(kt)                                                                           \
             __syncthreads(); /* tile kt+1 landed for everyone; buffer kt&1 is free */              \
             K_STAMP(3 + 2 * (kt))                                                                  \
             if (MORE2) stage_a(kt + 2, kt & 1, X_ON);                                                  \
