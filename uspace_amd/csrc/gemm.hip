@@ -71,7 +71,7 @@ constexpr int BK = 64;           // bf16 elements per K step (128 B per LDS row)
 #if !USPACE_LAB
 #if defined(USPACE_ABLATE_NOSTORE) || defined(USPACE_ABLATE_NOEPI) || defined(USPACE_ABLATE_NOGELU) || defined(USPACE_DMA_FLAT) || \
     defined(USPACE_RING_PREFETCH_ALL) || defined(USPACE_TINY_UNROLL) || defined(USPACE_EARLY_BARRIER) || defined(USPACE_TALL_COST) || defined(USPACE_CHAIN) || \
-    defined(USPACE_CHAIN_ABL) || defined(USPACE_CHAIN_DMA8) || defined(USPACE_CHAIN_SPLIT) || defined(USPACE_CHAIN_BODY) || defined(USPACE_FULL_LINES) || defined(USPACE_KTRACE)
+    defined(USPACE_CHAIN_ABL) || defined(USPACE_CHAIN_DMA8) || defined(USPACE_CHAIN_SPLIT) || defined(USPACE_CHAIN_BODY) || defined(USPACE_FULL_LINES) || defined(USPACE_KTRACE) || defined(USPACE_MMA_ORDER)
 #error "measurement switches need -DUSPACE_LAB=1 (tools/lab/build_variant.sh); the product build takes none"
 #endif
 #define USPACE_ABLATE_NOSTORE 0
@@ -99,6 +99,12 @@ constexpr int BK = 64;           // bf16 elements per K step (128 B per LDS row)
 #endif
 #ifndef USPACE_TINY_UNROLL
 #define USPACE_TINY_UNROLL 1
+#endif
+#ifndef USPACE_MMA_ORDER
+// order of a phase's independent MFMAs: 1 = snake over the wave's sub-tiles (exactly one operand register changes between consecutive MFMAs: the pure
+// MFMA stream sustains 2.07 instead of 2.03 PFLOP/s on random operands, `profiles/r04_mfma_power_lab.txt`; fc1 -1 % in the A/B, bit-equal), 0 = rows outer /
+// columns inner (rounds 1-4), 2 = columns outer.  0 and 2 are lab settings.
+#define USPACE_MMA_ORDER 1
 #endif
 #ifndef USPACE_KTRACE
 #define USPACE_KTRACE 0          // 1: cycle stamps (s_memtime) around the K loop's barriers of two workgroups, read with uspace_lab_gemm_trace (tools/lab/gemm_trace.py)
@@ -466,11 +472,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
     _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_)                                               \
         dst[j_] = *(const bf16x8*)((base) + w_lds + j_ * 16 * ROW_BYTES + (ck));
 #define LOAD_X(dst, base, ck) if (X_ON) dst = *(const bf16x8*)((base) + x_lds + (ck));
+#if USPACE_MMA_ORDER == 2
 #define MMA(af, wf, mh, ilo, ihi)                                                                   \
-    _Pragma("unroll") for (int i_ = (ilo); i_ < (ihi); ++i_)                                        \
-        _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_)                                           \
+    _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_)                                               \
+        _Pragma("unroll") for (int i_ = (ilo); i_ < (ihi); ++i_)                                    \
             acc[(mh) * HM + i_][j_] =                                                               \
                 __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j_], af[i_], acc[(mh) * HM + i_][j_], 0, 0, 0);
+#else
+#define MMA(af, wf, mh, ilo, ihi)                                                                   \
+    _Pragma("unroll") for (int i_ = (ilo); i_ < (ihi); ++i_)                                        \
+        _Pragma("unroll") for (int jj_ = 0; jj_ < TN; ++jj_) {                                      \
+            const int j_ = (USPACE_MMA_ORDER == 1 && (i_ & 1)) ? TN - 1 - jj_ : jj_;                \
+            acc[(mh) * HM + i_][j_] =                                                               \
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j_], af[i_], acc[(mh) * HM + i_][j_], 0, 0, 0); \
+        }
+#endif
 #define MMA_X(xf, wf)                                                                               \
     if (XTRA && X_ON) {                                                                             \
         _Pragma("unroll") for (int j_ = 0; j_ < XN; ++j_)                                           \
