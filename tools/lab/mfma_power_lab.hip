@@ -95,9 +95,10 @@ __global__ __launch_bounds__(512, 1) void mfma_stream(const uint4* __restrict__ 
 
 // The GEMM's K loop minus its global side: per sweep of 32 MFMAs the wave re-reads its 12 fragments from LDS into the other register set
 // (ds_read_b128, 24 per 64 MFMAs as in the product loop).  LDSR = 0: same loop without the reads.
-template <int LDSR, int ILV = 0, int WIDTH = 16, int GLB = 0>
+template <int LDSR, int ILV = 0, int WIDTH = 16, int GLB = 0, int DMA = 0>
 __global__ __launch_bounds__(512, 1) void mfma_lds_stream(const uint4* __restrict__ src, float* __restrict__ sink, unsigned long long* __restrict__ ticks, int iters) {
-    __shared__ uint4 lds[4 * 12 * 64];      // 48 KB: a wave pair shares 12 KB of fragments
+    __shared__ uint4 lds[4 * 12 * 64 + 8 * 8 * 64];      // 48 KB: a wave pair shares 12 KB of fragments; + 64 KB that the LDS-DMA pieces land in
+    uint4* const dma_dst = lds + 4 * 12 * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 4 * 12 * 64; i += blockDim.x) lds[i] = src[i % (2 * 12 * 64)];
     __syncthreads();
@@ -139,11 +140,25 @@ __global__ __launch_bounds__(512, 1) void mfma_lds_stream(const uint4* __restric
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (8 + j < LDSR) b[r ^ 1][j] = frag(8 + j);
+            if constexpr (DMA != 0) {
+                // LDS-DMA pieces (1 KB per wave each) from an L2-resident source into a scratch region of the LDS nobody reads
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+                for (int d = 0; d < DMA; ++d)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dma_dst + (wave * 8 + d) * 64), 16, (uint32_t)((d * 64 + lane) * 16), 0, 0, 0);
+            }
             if constexpr (ILV == 0) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[r][j], a[r][i], acc[i][j], 0, 0, 0);
+            if constexpr (DMA != 0 && ILV != 0) {
+#pragma unroll
+                for (int q = 0; q < DMA; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
             if constexpr (ILV != 0) {
 #pragma unroll
                 for (int q = 0; q < LDSR; ++q) {
@@ -165,20 +180,21 @@ __global__ __launch_bounds__(512, 1) void mfma_lds_stream(const uint4* __restric
     if (blockIdx.x == 0 && lane == 0) atomicMax(ticks, __builtin_readcyclecounter() - t0);
 }
 
-template <int LDSR, int ILV = 0, int WPS = 2, int WIDTH = 16, int GLB = 0>
+template <int LDSR, int ILV = 0, int WPS = 2, int WIDTH = 16, int GLB = 0, int DMA = 0>
 static void run_lds(const char* name, const uint4* src, float* sink, unsigned long long* ticks, int iters) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipFuncSetAttribute((const void*)mfma_lds_stream<LDSR, ILV, WIDTH, GLB>, hipFuncAttributeMaxDynamicSharedMemorySize, 0);
-    hipLaunchKernelGGL((mfma_lds_stream<LDSR, ILV, WIDTH, GLB>), dim3(256), dim3(256 * WPS), 0, 0, src, sink, ticks, iters / 10);
+    hipFuncSetAttribute((const void*)mfma_lds_stream<LDSR, ILV, WIDTH, GLB, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, 0);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((mfma_lds_stream<LDSR, ILV, WIDTH, GLB, DMA>), dim3(256), dim3(256 * WPS), 0, 0, src, sink, ticks, iters / 10);
     hipDeviceSynchronize();
     float best = 1e30f;
     unsigned long long tk = 0;
     for (int rep = 0; rep < 3; ++rep) {
         hipMemset(ticks, 0, 8);
         hipEventRecord(e0);
-        hipLaunchKernelGGL((mfma_lds_stream<LDSR, ILV, WIDTH, GLB>), dim3(256), dim3(256 * WPS), 0, 0, src, sink, ticks, iters);
+        hipLaunchKernelGGL((mfma_lds_stream<LDSR, ILV, WIDTH, GLB, DMA>), dim3(256), dim3(256 * WPS), 0, 0, src, sink, ticks, iters);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
@@ -264,5 +280,10 @@ int main() {
     run_lds<12, 0, 2, 8>("12 KB per 32 MFMAs as 24 ds_read_b64, burst", dr, sink, ticks, iters / 2);
     run_lds<12, 0, 2, 16, 4>("8 ds_read_b128 + 4 global 16-byte loads per 32, burst", dr, sink, ticks, iters / 2);
     run_lds<12, 0, 2, 16, 12>("12 global 16-byte loads per 32 (L2-resident), no LDS", dr, sink, ticks, iters / 2);
+    run_lds<0, 0, 2, 16, 0, 4>("no reads, 4 LDS-DMA pieces per 32 MFMAs (the 8-wave loop's rate), burst", dr, sink, ticks, iters / 2);
+    run_lds<0, 1, 2, 16, 0, 4>("no reads, 4 LDS-DMA pieces per 32, one every 2 MFMAs", dr, sink, ticks, iters / 2);
+    run_lds<12, 0, 2, 16, 0, 4>("12 reads + 4 LDS-DMA pieces per 32, burst (the 8-wave loop)", dr, sink, ticks, iters / 2);
+    run_lds<8, 1, 1, 16, 0, 4>("8 reads + 4 LDS-DMA pieces per 32, spread (the 4-wave form)", dr, sink, ticks, iters / 2);
+    run_lds<0, 1, 1, 16, 0, 4>("no reads, 4 LDS-DMA pieces per 32, spread", dr, sink, ticks, iters / 2);
     return 0;
 }
