@@ -15,52 +15,17 @@
 //     are 16-byte (fp32) or 8-byte (bf16) vectors along N;
 //   * workgroup ids are remapped so that each XCD (private L2) owns a contiguous run of tiles.
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 #include <vector>
 
 #include "common.h"
+#include "gemm_args.h"
 
 namespace {
 
-struct GemmArgs {
-    const bf16_t* A;
-    const bf16_t* A2;
-    const bf16_t* W;
-    const float* bias;
-    const float* resid;
-    float* out_f32;
-    bf16_t* out_bf16;
-    int M, N, K, K1;
-    int lda, lda2, ldw, ld_resid, ld_f32, ld_bf16;
-    int tiles_m, tiles_n;
-    int n_slab, k1_log2;  // K is n_slab slabs of K1 = 2^k1_log2 (n_slab > 1); slab s reads A rows shifted by slab_shift[s]
-    int slab_shift[9];    // (3x3 convolution over a zero-bordered NHWC map: 9 taps); 0 for the long-skip's second slab
-    int m_main, n_strip; // XTRA: rows [m_main, M) are handled as n_strip strips of 16 rows, each owned by the workgroups of one tile row
-    // LayerNorm folded through the GEMM (DESIGN.md "LayerNorm folding"):
-    //   producer (USPACE_EPI_CEN_OUT): also writes out_cen = bf16(v - row_c[m]) and, per row and N tile, the partial
-    //                                  sums (sum, sum of squares) of v - row_c[m] to part_out[m][tiles_n][2];
-    //   consumer (USPACE_EPI_LN_IN):   A holds such centred rows; y = rstd[m] * (acc - d[m] * colsum[n]) + bias[n] with
-    //                                  d, rstd from part_in[m][np_in][2]; N tile 0 writes c_out[m] = row_c[m] + d[m].
-    const float* row_c;
-    bf16_t* out_cen;
-    float* part_out;
-    const float* part_in;
-    const float* colsum;
-    float* c_out;
-    const float* row_add;   // USPACE_EPI_RANK1: acc[m][n] += row_add[m] * col_add[n]
-    const float* col_add;
-    int ld_cen, np_in;
-    float inv_d, eps;
-    int wide;   // bf16 outputs (out_bf16, out_cen) allow 16-byte stores: row strides % 8 == 0, bases 16-byte aligned
-    // ring form (NST > 2, the K-split launches): gridDim.y workgroups per tile, each over nk_split K tiles; split s writes
-    // its raw fp32 sums to out_f32 + s * split_stride; splitk_finish_kernel adds them and applies the real epilogue
-    int nk_split;
-    long split_stride;
-    float* split_ws;          // host side only: workspace for the K-split form (NULL: never split)
-    size_t split_ws_bytes;
-};
+using namespace usgemm;
 
-constexpr int BK = 64;           // bf16 elements per K step (128 B per LDS row)
 
 // Measurement switches.  The A/B and ablation builds behind `profiles/r0*_gemm_ablation.md` exist only under -DUSPACE_LAB=1, which
 // `tools/lab/build_variant.sh` passes and `csrc/Makefile` never does (it builds with -DUSPACE_LAB=0 -Werror=undef): a product build
@@ -1075,37 +1040,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
 #endif
 }
 
-// Tiling plan: how many BM-row tile rows get their own workgroups, the remaining rows being cut into n_strip strips of 16
-// rows owned by that many tile rows.  Cost model: rounds of workgroups over the CUs; a strip owner does one more 16-row
-// MFMA tile (1/16 of a 256-row tile, 1/8 of a 128-row one), which costs its share of the work plus a tail.
-struct Plan {
-    int tiles_m, m_main, n_strip;
-};
-
-inline double strip_factor(const Plan& p, int BM) {
-    if (p.n_strip <= 0) return 1.0;
-    return 1.0 + ((double)p.n_strip / p.tiles_m) * (16.0 / BM) + 0.01;
-}
-
-inline Plan plan_rows(int M, int BM, int tiles_n, int wg_per_round) {
-    const int full = M / BM;
-    Plan best{us_cdiv(M, BM), 0, 0};
-    best.m_main = M;
-    double best_cost = (double)us_cdiv(best.tiles_m * tiles_n, wg_per_round);
-    for (int tm = full; tm >= 1 && tm >= full - 8; --tm) {
-        const int rem = M - tm * BM;
-        if (rem <= 0) continue;
-        if (rem > 16 * tm) break;                     // at most one strip per tile row
-        const Plan p{tm, tm * BM, us_cdiv(rem, 16)};
-        const double cost = (double)us_cdiv(tm * tiles_n, wg_per_round) * strip_factor(p, BM);
-        if (cost < best_cost - 1e-9) {
-            best_cost = cost;
-            best = p;
-        }
-    }
-    return best;
-}
-
 template <int BM, int BN, int WM, int WN, int FLAGS, int NST = 2>
 int launch(const GemmArgs& a, hipStream_t s, int wg_per_round) {
     GemmArgs g = a;
@@ -1244,6 +1178,15 @@ inline GemmArgs row_slice(const GemmArgs& a, int m_lo, int m_hi) {
     return g;
 }
 
+// 256 x 256 launches: 0 = the four-wave form (gemm4.hip) wherever us_gemm4_ok() admits it, 1 = the 8-wave template only (A/B runs, parity
+// tests), 2 = the four-wave form for EVERY launch it admits, whatever tile form the planner would pick (tests of small shapes)
+std::atomic<int> g_big_form{0};
+template <int FLAGS>
+int launch_big(const GemmArgs& a, hipStream_t s) {
+    if (g_big_form.load(std::memory_order_relaxed) == 0 && us_gemm4_ok(a, FLAGS, false)) return us_gemm4_launch(a, FLAGS, s, false);
+    return launch<256, 256, 2, 4, FLAGS>(a, s, 256);
+}
+
 enum TileChoice { TILE_BIG = 0, TILE_MID = 1, TILE_SMALL = 2, TILE_SPLIT = 3, TILE_TALL = 4, TILE_TINY = 5 };
 
 // Four tile configurations, chosen by a round-count cost model (unit: one round of 256x256 tiles):
@@ -1327,6 +1270,7 @@ inline TileChoice producer_tile(TileChoice tc, int N) {
 
 template <int FLAGS>
 int dispatch_tile(const GemmArgs& a, hipStream_t s) {
+    if (g_big_form.load(std::memory_order_relaxed) == 2 && us_gemm4_ok(a, FLAGS, true)) return us_gemm4_launch(a, FLAGS, s, true);
     int m1 = 0;
     TileChoice tc = choose_tile(a.M, a.N, &m1);
     if constexpr ((FLAGS & USPACE_EPI_CEN_OUT) != 0) tc = producer_tile(tc, a.N);
@@ -1355,11 +1299,11 @@ int dispatch_tile(const GemmArgs& a, hipStream_t s) {
     }
 #endif
     switch (tc) {
-        case TILE_BIG: return launch<256, 256, 2, 4, FLAGS>(a, s, 256);
+        case TILE_BIG: return launch_big<FLAGS>(a, s);
         case TILE_MID: return launch<192, 256, 2, 4, FLAGS>(a, s, 256);
         case TILE_TALL: return launch<256, 128, 4, 2, FLAGS>(a, s, 256);
         case TILE_SPLIT: {
-            int rc = launch<256, 256, 2, 4, FLAGS>(row_slice(a, 0, m1), s, 256);
+            int rc = launch_big<FLAGS>(row_slice(a, 0, m1), s);
             if (rc != USPACE_OK) return rc;
             return launch<128, 128, 2, 2, FLAGS>(row_slice(a, m1, a.M), s, 512);
         }
@@ -1408,8 +1352,30 @@ int wide_ok(const GemmArgs& g, int epi_flags) {
 
 }  // namespace
 
+extern "C" int uspace_gemm_set_big_form(int form) {
+    if (form < 0 || form > 2) return USPACE_ERR_ARG;
+    return g_big_form.exchange(form, std::memory_order_relaxed);
+}
+
+extern "C" int uspace_gemm_takes_form4(int M, int N, int K, int K1, int epi_flags) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int form = g_big_form.load(std::memory_order_relaxed);
+    if (form == 1) return 0;
+    int m1 = 0;
+    const TileChoice tc = refine_small((epi_flags & USPACE_EPI_CEN_OUT) ? producer_tile(choose_tile(M, N, &m1), N) : choose_tile(M, N, &m1), M, N, K,
+                                       (epi_flags & USPACE_EPI_CEN_OUT) != 0);
+    if (tc != TILE_BIG && form != 2) return 0;
+    GemmArgs g{};
+    g.M = M; g.N = N; g.K = K; g.K1 = (K1 > 0 && K1 < K) ? K1 : K;
+    g.n_slab = g.K1 < K ? 2 : 1;
+    g.wide = 1;
+    return us_gemm4_ok(g, epi_flags, form == 2) ? 1 : 0;
+}
+
 extern "C" int uspace_gemm_part_slots_k(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return USPACE_ERR_ARG;
+    // (forced four-wave form: 256-wide tiles wherever a producer launch of these sizes can take it)
+    if (g_big_form.load(std::memory_order_relaxed) == 2 && uspace_gemm_takes_form4(M, N, K, K, USPACE_EPI_CEN_OUT | USPACE_EPI_BIAS | USPACE_EPI_OUT_F32)) return N / 256;
     int m1 = 0;
     const TileChoice tc = refine_small(producer_tile(choose_tile(M, N, &m1), N), M, N, K, true);
     return us_cdiv(N, tc == TILE_TINY ? 64 : (tc == TILE_SMALL || tc == TILE_TALL) ? 128 : 256);
