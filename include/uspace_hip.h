@@ -13,8 +13,7 @@
  *     end of this header (not thread-safe: one measuring thread); (2) the LayerNorm-fold switch
  *     uspace_uvit_set_ln_fold / _get_ln_fold (atomic; default on); (3) per kernel, the set of devices on which it has
  *     been opted in to more than 64 KiB of dynamic LDS (atomic bit mask; any number of GPUs per process); (4) a
- *     mutex-protected cache of the parameter layout derived from each distinct uspace_uvit_config; (5) the GEMM form
- *     switch uspace_gemm_set_big_form (atomic; default 0).
+ *     mutex-protected cache of the parameter layout derived from each distinct uspace_uvit_config.
  * bf16 values cross the boundary as raw uint16_t (upper half of an IEEE fp32, RNE).
  */
 #ifndef USPACE_HIP_H
@@ -27,7 +26,7 @@
 extern "C" {
 #endif
 
-#define USPACE_ABI_VERSION 10
+#define USPACE_ABI_VERSION 9
 
 #define USPACE_OK 0
 #define USPACE_ERR_ARG (-1)         /* bad pointer / size / unsupported shape */
@@ -124,18 +123,6 @@ USPACE_API int uspace_gemm_part_slots(int M, int N);       /* the largest count 
 /* ... of the producer GEMM with this K.  (Launches of few tiles use 64-wide tiles -- more slots -- whatever their K; K only
  * selects which K loop those tiles run, so today the count does not depend on it.  Callers pass the real K all the same.) */
 USPACE_API int uspace_gemm_part_slots_k(int M, int N, int K);
-
-/* Process-wide switch for launches of 256x256 tiles: 0 (default) = the four-wave form -- 4 waves x (128 x 128), accumulators in
- * AGPRs, K loop in hand-scheduled assembly (csrc/gemm4.hip, csrc/kloop4.inc) -- wherever the launch admits it (N % 256 == 0, tile
- * rows + 16-row strips, K % 128 == 0, at most two K slabs, 16-byte bf16 rows), the 8-wave template elsewhere; 1 = the 8-wave
- * template only (A/B measurements, parity tests); 2 = the four-wave form for every launch that admits it, whatever tile form
- * the planner would pick (tests on small shapes; uspace_gemm_part_slots_k follows).  Returns the previous value,
- * USPACE_ERR_ARG for anything else.  Outputs of the
- * two forms are bit-equal except where a residual is added (the four-wave form adds it behind the K loop: fp32 rounding) and in
- * LayerNorm partial sums (added over 2 instead of 4 column groups). */
-USPACE_API int uspace_gemm_set_big_form(int form);
-/* would a launch of these sizes take the four-wave form under the current switch?  (host-side; 1 / 0) */
-USPACE_API int uspace_gemm_takes_form4(int M, int N, int K, int K1, int epi_flags);
 
 /* Which tile configuration uspace_gemm_bf16 uses for an [M, N] output (host-side planning, no GPU work):
  * 0 = 256x256 tiles, 1 = 192x256, 2 = 128x128, 3 = rows [0, *split_rows) as 256x256 and the rest as 128x128,

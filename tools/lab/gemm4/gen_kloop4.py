@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generator of the hand-scheduled K loop of the four-wave GEMM form (kloop4.inc).
 
-    python3 uspace_amd/csrc/gen_kloop4.py [--check] [--out=path] [knob=value ...]
+    python3 tools/lab/gemm4/gen_kloop4.py [--check] [--out=path] [knob=value ...]
 
 Why a generator: the loop is one `asm volatile` block with fixed register numbers (256 accumulator registers in the AGPR
 half of the file, two 64-register fragment sets, hand-placed LDS reads / LDS-DMA pieces between the MFMAs); neither the
@@ -27,8 +27,8 @@ Forms (one text each, KLOOP4_TEXT_<x><p>):
          LDS 128 KiB + stage * 2 KiB), one more fragment read and 4 more MFMAs per k-slice into four accumulators that live in
          compiler-allocated VGPRs (operands x0..x3); wave row wm takes the strip's column sub-tiles 4 wm .. 4 wm + 3 of its half.
   p = 1: residual forms: one 4-byte load per lane and K tile that touches a 128-byte line of the fp32 residual block the epilogue
-         will add (its HBM read then runs under the K loop instead of in front of the epilogue); the descriptor's range makes
-         all but eight of them no-ops, the start value of the offset register chooses which eight K tiles carry them.
+         will add (its HBM read then runs under the K loop instead of in front of the epilogue); lanes / K tiles beyond the block are
+         out of the descriptor's range and fetch nothing.
 
 The block's contract with the C++ around it (gemm4.hip): inputs are read-only operands; every register it writes is either
 an in/out operand or fixed and listed as a clobber (so the compiler keeps out of them and the kernel descriptor covers them);
@@ -50,7 +50,9 @@ KNOBS = dict(
     READ_ORDER="wa",    # order of a phase's 16 fragment reads: "wa" = W0..7 then A0..7, "aw", "mix" = W0 A0 W1 A1 ...
     X_AT=40,            # strip form: the 4 strip MFMAs of a phase go behind this MFMA
     PAD=0,              # s_nop 0 in front of the loop label (code placement: 4-byte steps)
-    TRACE=0,            # 1: s_memtime at block entry, loop entry and loop exit (three 64-bit outputs t0, t1, t2)
+    DMA_AUX="",         # cache-policy bits of the LDS-DMA loads: "" | "nt" | "sc1" | "sc0 sc1" (lab)
+    TRACE=0,            # 1: s_memtime at block entry, loop entry and loop exit (three 64-bit outputs t0, t1, t2); 2: also the cycles spent in
+                        #    front of every barrier: waiting for memory / LDS counters (tw1) and for the other waves (tw2), summed over the loop
 )
 
 # ---- fixed registers of the block -------------------------------------------------------------------------------
@@ -63,7 +65,8 @@ S_RSA, S_RSW = 36, 40        # buffer descriptors s[36:39], s[40:43]
 S_PA, S_PW = 44, 51          # soffsets of pieces 1..7: s44..s50 (A), s51..s57 (W)
 S_M0, S_CNT, S_M0SAVE, S_SLAB = 58, 59, 60, 61
 S_RSR = 64                   # s[64:67]: descriptor of this wave's residual block (prefetch)
-S_FIRST, S_LAST = 36, 67
+S_TW = 68                    # TRACE=2: s[68:69], s[70:71], s[72:73] stamps, s74 / s75 the two sums
+S_FIRST, S_LAST = 36, 75
 STAGE_BYTES = 65536
 W_OFF = 32768
 X_OFF = 131072               # strip rows: 2 KiB per stage behind the two stages
@@ -132,6 +135,9 @@ def read_list(stage, ks, st, order, xtra):
     return out
 
 
+DMA_AUX = [""]
+
+
 def dma_list(stage, xtra):
     """the LDS-DMA pieces of one K tile into `stage`: (m0 write, load) pairs, A and W alternating; the strip's piece comes 13th
     (it belongs to the pieces issued in phase B)"""
@@ -143,11 +149,11 @@ def dma_list(stage, xtra):
             rs = S_RSW if op else S_RSA
             soff = "0" if p == 0 else f"s{(S_PW if op else S_PA) + p - 1}"
             vo = "%[vow]" if op else "%[voa]"
-            out.append((m0, f"buffer_load_dwordx4 {vo}, s[{rs}:{rs + 3}], {soff} offen lds"))
+            out.append((m0, f"buffer_load_dwordx4 {vo}, s[{rs}:{rs + 3}], {soff} offen{DMA_AUX[0]} lds"))
     if xtra:   # this wave's 8 strip rows ((wave & 1) * 8 ...): %[m0x] = LDS base + X_OFF + (wave & 1) * 1024
         imm = stage * 2048
         m0 = f"s_add_i32 m0, %[m0x], 0x{imm:x}" if imm else "s_mov_b32 m0, %[m0x]"
-        out.insert(12, (m0, f"buffer_load_dwordx4 %[vox], s[{S_RSA}:{S_RSA + 3}], 0 offen lds"))
+        out.insert(12, (m0, f"buffer_load_dwordx4 %[vox], s[{S_RSA}:{S_RSA + 3}], 0 offen{DMA_AUX[0]} lds"))
     return out
 
 
@@ -188,7 +194,12 @@ def tile(k, stage, dma, nxt, xtra, pf, tag):
     for x, s in zip(m, slots):
         L.append(x)
         L += s
-    if nxt:
+    if nxt and k["TRACE"] == 2:
+        L += [f"s_memtime s[{S_TW}:{S_TW + 1}]", f"s_waitcnt vmcnt({1 if pf else 0}) lgkmcnt(0)", f"s_memtime s[{S_TW + 2}:{S_TW + 3}]", "s_waitcnt lgkmcnt(0)", "s_barrier",
+              f"s_memtime s[{S_TW + 4}:{S_TW + 5}]", "s_waitcnt lgkmcnt(0)",
+              f"s_sub_u32 s{S_TW + 4}, s{S_TW + 4}, s{S_TW + 2}", f"s_sub_u32 s{S_TW + 2}, s{S_TW + 2}, s{S_TW}",
+              f"s_add_u32 s{S_TW + 6}, s{S_TW + 6}, s{S_TW + 2}", f"s_add_u32 s{S_TW + 7}, s{S_TW + 7}, s{S_TW + 4}"]
+    elif nxt:
         L.append(f"s_waitcnt vmcnt({1 if pf else 0}) lgkmcnt(0)")
         L.append("s_barrier")
     else:
@@ -258,6 +269,8 @@ def kloop(k, xtra, pf):
     if tr:
         L += ["s_memtime %[t1]"]
     L += ["s_waitcnt lgkmcnt(0)"]
+    if tr == 2:
+        L += [f"s_mov_b32 s{S_TW + 6}, 0", f"s_mov_b32 s{S_TW + 7}, 0"]
     L += [f"s_cmp_eq_u32 s{S_CNT}, 0", "s_cbranch_scc1 .Lk4_tail_%="]
     L += ["s_nop 0"] * k["PAD"]
     L.append(".Lk4_loop_%=:")
@@ -269,6 +282,8 @@ def kloop(k, xtra, pf):
     L += tile(k, 1, False, False, xtra, pf, "t1")
     if tr:
         L += ["s_memtime %[t2]", "s_waitcnt lgkmcnt(0)"]
+    if tr == 2:
+        L += [f"s_mov_b32 %[tw1], s{S_TW + 6}", f"s_mov_b32 %[tw2], s{S_TW + 7}"]
     if pf:
         L += ["s_waitcnt vmcnt(0)"]     # the last prefetch load writes a register the compiler owns again behind this block
     # MFMA results -> v_accvgpr_read of the epilogue: the last MFMAs must have written back (8 passes: 11+ wait states)
@@ -293,7 +308,7 @@ def read_row_macro(i):
 
 
 def render(k):
-    H = ["// GENERATED by gen_kloop4.py -- do not edit; regenerate with `python3 uspace_amd/csrc/gen_kloop4.py`",
+    H = ["// GENERATED by gen_kloop4.py -- do not edit; regenerate with `python3 tools/lab/gemm4/gen_kloop4.py`",
          "// knobs: " + " ".join(f"{a}={b}" for a, b in sorted(k.items())),
          "#pragma once", "",
          f"#define KLOOP4_TRACE {k['TRACE']}", ""]
@@ -330,6 +345,7 @@ def main(argv):
             k[key] = type(KNOBS[key])(val)
         else:
             raise SystemExit(__doc__)
+    DMA_AUX[0] = (" " + k["DMA_AUX"]) if k["DMA_AUX"] else ""
     txt = render(k)
     if check:
         cur = open(out).read() if os.path.exists(out) else ""

@@ -1,5 +1,7 @@
-"""The four-wave GEMM form (csrc/gemm4.hip: 4 waves x 128 x 128, accumulators in AGPRs, K loop in assembly -- csrc/kloop4.inc) against
-the 8-wave template it replaces on 256 x 256 launches, both through the C-ABI (uspace_gemm_set_big_form), and against the oracle.
+"""LAB test (round 5; the form was measured and not landed: profiles/r05_gemm4.md).  Needs the lab library:
+    tools/lab/gemm4/build.sh && USPACE_HIP_LIB=tools/lab/_build/lib_gemm4.so python -m pytest tools/lab/gemm4/test_form4.py -m gpu -q
+The four-wave GEMM form (gemm4.hip: 4 waves x 128 x 128, accumulators in AGPRs, K loop in assembly -- kloop4.inc) against the 8-wave
+template on 256 x 256 launches, both through the C-ABI (uspace_lab_gemm_set_big_form), and against the oracle.
 Reference operators: nn.Linear of libs/timm.py:106-112 (fc1 / fc2), libs/uvit.py:89,116 (qkv / proj), :158-159 (skip_linear).
 
 Without a residual the two forms run the same MFMAs in the same order per output element: outputs must be BIT-equal.  With a
@@ -19,9 +21,11 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def hip():
     from uspace_amd import _hip
-    _hip.lib()
+    lib = _hip.lib()
+    if not hasattr(lib, "uspace_lab_gemm_set_big_form"):
+        pytest.skip("the loaded library has no four-wave form: build tools/lab/gemm4 and point USPACE_HIP_LIB at it")
     yield _hip
-    _hip.lib().uspace_gemm_set_big_form(0)
+    lib.uspace_lab_gemm_set_big_form(1)
 
 
 def _rand(rng, *shape, scale=1.0):
@@ -33,17 +37,17 @@ def _both_forms(hip, fn):
     lib = hip.lib()
     out = []
     for form in (1, 2):
-        assert lib.uspace_gemm_set_big_form(form) in (0, 1, 2)
+        assert lib.uspace_lab_gemm_set_big_form(form) in (0, 1, 2)
         out.append(fn())
-    lib.uspace_gemm_set_big_form(0)
+    lib.uspace_lab_gemm_set_big_form(1)
     return out
 
 
 def _takes4(hip, *a):
     lib = hip.lib()
-    lib.uspace_gemm_set_big_form(2)
-    r = lib.uspace_gemm_takes_form4(*a)
-    lib.uspace_gemm_set_big_form(0)
+    lib.uspace_lab_gemm_set_big_form(2)
+    r = lib.uspace_lab_gemm_takes_form4(*a)
+    lib.uspace_lab_gemm_set_big_form(1)
     return r
 
 

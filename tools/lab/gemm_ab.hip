@@ -1,5 +1,7 @@
 // Interleaved A/B timing of two builds of libuspace_hip.so on the U-ViT GEMM shapes (run on the GPU box):
-//   tools/lab/_build/gemm_ab <libA.so> <libB.so> [M] [rounds] [reps] [D]
+//   tools/lab/_build/gemm_ab <libA.so> <libB.so> [M] [rounds] [reps] [D] [formA] [formB]
+// formA / formB (round 5): uspace_gemm_set_big_form of each library (0 = four-wave form where it applies, 1 = 8-wave only); to compare the
+// two forms of ONE build pass a copy of the library as libB (the same path would be the same loaded object and share the switch)
 // Both libraries run the same launches alternately inside one process (box-to-box and thermal drift is larger than
 // the differences of interest); prints the median and minimum per variant and whether the outputs agree.
 #include <dlfcn.h>
@@ -66,8 +68,15 @@ int main(int argc, char** argv) {
     const int rounds = argc > 4 ? atoi(argv[4]) : 7;
     const int reps = argc > 5 ? atoi(argv[5]) : 10;
     const int D = argc > 6 ? atoi(argv[6]) : 1024, Bsz = M / 257 > 0 ? M / 257 : 1;
+    for (int v = 0; v < 2; ++v) {
+        if (argc > 7 + v) {
+            typedef int (*form_fn)(int);
+            form_fn f = (form_fn)dlsym(L[v].h, "uspace_gemm_set_big_form");
+            if (!f || f(atoi(argv[7 + v])) < 0) { fprintf(stderr, "library %d: no form switch / bad form\n", v); return 2; }
+        }
+    }
     constexpr int B_ = USPACE_EPI_BIAS, G_ = USPACE_EPI_GELU, R_ = USPACE_EPI_RESIDUAL, F_ = USPACE_EPI_OUT_F32, H_ = USPACE_EPI_OUT_BF16, C_ = USPACE_EPI_CEN_OUT,
-                  L_ = USPACE_EPI_LN_IN;
+                  L_ = USPACE_EPI_LN_IN, K_ = USPACE_EPI_RANK1;
     std::mt19937 rng(99);
     std::normal_distribution<float> nd(0.f, 1.f);
     const size_t nA = (size_t)M * 4 * D, nW = (size_t)4 * D * 4 * D;
@@ -120,9 +129,9 @@ int main(int argc, char** argv) {
         {"qkv  L|B|H", 3 * D, D, L_ | B_ | H_, 21},
         {"proj C|B|R|F", D, D, C_ | B_ | R_ | F_, 21},
         {"fc1  L|B|G|H", 4 * D, D, L_ | B_ | G_ | H_, 21},
-        {"fc2  C|B|R|F|H", D, 4 * D, C_ | B_ | R_ | F_ | H_, 10},
+        {"fc2  C|B|R|F", D, 4 * D, C_ | B_ | R_ | F_, 10},        // in-blocks since round 4: the centred copy IS the skip
         {"fc2  B|R|F|H", D, 4 * D, B_ | R_ | F_ | H_, 11},
-        {"skip C|B|F", D, 2 * D, C_ | B_ | F_, 10},
+        {"skip K|C|B|F", D, 2 * D, K_ | C_ | B_ | F_, 10},
         {"attention", 0, 0, 0, 21},
     };
     hipEvent_t e0, e1;
@@ -143,6 +152,7 @@ int main(int argc, char** argv) {
             ext.split_ws_bytes = ws_bytes;
             if (s.flags & C_) { ext.row_c = dC; ext.out_cen = dCen[v]; ext.ld_cen = D; ext.part_out = dPout[v]; }
             if (s.flags & L_) { ext.part_in = dPin; ext.np_in = 4; ext.colsum = dCs; ext.row_c = dC; ext.c_out = dCout[v]; }
+            if (s.flags & K_) { ext.row_add = dC; ext.col_add = dCs; }
             const bool skip = s.K == 2 * D;
             // resid_in read from dR, result to dF[v]: repeated launches are idempotent
             const int rc = L[v].gemm(dA, skip ? D : s.K, skip ? dA2 : nullptr, skip ? D : 0, skip ? D : s.K, dW, s.K, M, s.N, s.K, s.flags, db,

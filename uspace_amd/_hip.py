@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("USPACE_HIP_LIB") or os.path.join(_HERE, "libuspace_hi
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_OUT_BF16 = 1, 2, 4, 8, 16
 EPI_CEN_OUT, EPI_LN_IN, EPI_RANK1 = 32, 64, 128          # uspace_gemm_bf16_ext only (LayerNorm folded through the GEMMs)
 
-ABI_VERSION = 10
+ABI_VERSION = 9
 
 _ERR = {-1: "USPACE_ERR_ARG", -2: "USPACE_ERR_LAUNCH", -3: "USPACE_ERR_WORKSPACE"}
 
@@ -71,8 +71,6 @@ SIGNATURES = {
     "uspace_center_rows": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "uspace_uvit_set_ln_fold": (_I, [_I]),
     "uspace_uvit_get_ln_fold": (_I, []),
-    "uspace_gemm_set_big_form": (_I, [_I]),
-    "uspace_gemm_takes_form4": (_I, [_I, _I, _I, _I, _I]),
     "uspace_gemm_tile_choice": (_I, [_I, _I, ctypes.POINTER(_I)]),
     "uspace_gemm_plan": (_I, [_I, _I, ctypes.POINTER(_I)]),
     "uspace_gemm_plan_k": (_I, [_I, _I, _I, _I, ctypes.POINTER(_I)]),

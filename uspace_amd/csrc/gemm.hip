@@ -36,7 +36,7 @@ using namespace usgemm;
 #if !USPACE_LAB
 #if defined(USPACE_ABLATE_NOSTORE) || defined(USPACE_ABLATE_NOEPI) || defined(USPACE_ABLATE_NOGELU) || defined(USPACE_DMA_FLAT) || \
     defined(USPACE_RING_PREFETCH_ALL) || defined(USPACE_TINY_UNROLL) || defined(USPACE_EARLY_BARRIER) || defined(USPACE_TALL_COST) || defined(USPACE_CHAIN) || \
-    defined(USPACE_CHAIN_ABL) || defined(USPACE_CHAIN_DMA8) || defined(USPACE_CHAIN_SPLIT) || defined(USPACE_CHAIN_BODY) || defined(USPACE_FULL_LINES) || defined(USPACE_KTRACE) || defined(USPACE_MMA_ORDER)
+    defined(USPACE_CHAIN_ABL) || defined(USPACE_CHAIN_DMA8) || defined(USPACE_CHAIN_SPLIT) || defined(USPACE_CHAIN_BODY) || defined(USPACE_FULL_LINES) || defined(USPACE_KTRACE) || defined(USPACE_MMA_ORDER) || defined(USPACE_FORM4)
 #error "measurement switches need -DUSPACE_LAB=1 (tools/lab/build_variant.sh); the product build takes none"
 #endif
 #define USPACE_ABLATE_NOSTORE 0
@@ -76,6 +76,9 @@ using namespace usgemm;
 #endif
 #ifndef USPACE_FULL_LINES
 #define USPACE_FULL_LINES 0      // bit mask: 1 = bf16 outputs, 2 = fp32 output of interior tiles as 8 rows x 128 B per store instruction (A/B measurements)
+#endif
+#ifndef USPACE_FORM4
+#define USPACE_FORM4 0           // 1: 256x256 launches may take the four-wave form of tools/lab/gemm4/ (round 5; lab builds link gemm4.o)
 #endif
 #ifndef USPACE_CHAIN
 #define USPACE_CHAIN 0           // 1: multi-round store-only launches of 256x256 tiles take the chain form (gemm_chain.h)
@@ -1178,12 +1181,17 @@ inline GemmArgs row_slice(const GemmArgs& a, int m_lo, int m_hi) {
     return g;
 }
 
-// 256 x 256 launches: 0 = the four-wave form (gemm4.hip) wherever us_gemm4_ok() admits it, 1 = the 8-wave template only (A/B runs, parity
-// tests), 2 = the four-wave form for EVERY launch it admits, whatever tile form the planner would pick (tests of small shapes)
-std::atomic<int> g_big_form{0};
+#if USPACE_FORM4
+// Lab builds only (tools/lab/gemm4/: the four-wave form with the assembly K loop, measured in round 5 and not landed -- profiles/r05_gemm4.md).
+// 256 x 256 launches: 0 = the four-wave form wherever us_gemm4_ok() admits it, 1 = the 8-wave template only, 2 = the four-wave form for
+// EVERY launch it admits, whatever tile form the planner would pick (tests of small shapes)
+std::atomic<int> g_big_form{1};
+#endif
 template <int FLAGS>
 int launch_big(const GemmArgs& a, hipStream_t s) {
+#if USPACE_FORM4
     if (g_big_form.load(std::memory_order_relaxed) == 0 && us_gemm4_ok(a, FLAGS, false)) return us_gemm4_launch(a, FLAGS, s, false);
+#endif
     return launch<256, 256, 2, 4, FLAGS>(a, s, 256);
 }
 
@@ -1270,7 +1278,9 @@ inline TileChoice producer_tile(TileChoice tc, int N) {
 
 template <int FLAGS>
 int dispatch_tile(const GemmArgs& a, hipStream_t s) {
+#if USPACE_FORM4
     if (g_big_form.load(std::memory_order_relaxed) == 2 && us_gemm4_ok(a, FLAGS, true)) return us_gemm4_launch(a, FLAGS, s, true);
+#endif
     int m1 = 0;
     TileChoice tc = choose_tile(a.M, a.N, &m1);
     if constexpr ((FLAGS & USPACE_EPI_CEN_OUT) != 0) tc = producer_tile(tc, a.N);
@@ -1352,12 +1362,13 @@ int wide_ok(const GemmArgs& g, int epi_flags) {
 
 }  // namespace
 
-extern "C" int uspace_gemm_set_big_form(int form) {
+#if USPACE_FORM4
+extern "C" __attribute__((visibility("default"))) int uspace_lab_gemm_set_big_form(int form) {
     if (form < 0 || form > 2) return USPACE_ERR_ARG;
     return g_big_form.exchange(form, std::memory_order_relaxed);
 }
 
-extern "C" int uspace_gemm_takes_form4(int M, int N, int K, int K1, int epi_flags) {
+extern "C" __attribute__((visibility("default"))) int uspace_lab_gemm_takes_form4(int M, int N, int K, int K1, int epi_flags) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const int form = g_big_form.load(std::memory_order_relaxed);
     if (form == 1) return 0;
@@ -1371,11 +1382,14 @@ extern "C" int uspace_gemm_takes_form4(int M, int N, int K, int K1, int epi_flag
     g.wide = 1;
     return us_gemm4_ok(g, epi_flags, form == 2) ? 1 : 0;
 }
+#endif
 
 extern "C" int uspace_gemm_part_slots_k(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return USPACE_ERR_ARG;
+#if USPACE_FORM4
     // (forced four-wave form: 256-wide tiles wherever a producer launch of these sizes can take it)
-    if (g_big_form.load(std::memory_order_relaxed) == 2 && uspace_gemm_takes_form4(M, N, K, K, USPACE_EPI_CEN_OUT | USPACE_EPI_BIAS | USPACE_EPI_OUT_F32)) return N / 256;
+    if (g_big_form.load(std::memory_order_relaxed) == 2 && uspace_lab_gemm_takes_form4(M, N, K, K, USPACE_EPI_CEN_OUT | USPACE_EPI_BIAS | USPACE_EPI_OUT_F32)) return N / 256;
+#endif
     int m1 = 0;
     const TileChoice tc = refine_small(producer_tile(choose_tile(M, N, &m1), N), M, N, K, true);
     return us_cdiv(N, tc == TILE_TINY ? 64 : (tc == TILE_SMALL || tc == TILE_TALL) ? 128 : 256);

@@ -1,5 +1,5 @@
-// Argument block and row plan shared by the GEMM translation units (gemm.hip: the 8-wave template forms; gemm4.hip: the four-wave
-// form with the assembly K loop).
+// Argument block and row plan of the GEMM (gemm.hip), shared with the lab's four-wave form (tools/lab/gemm4/gemm4.hip: measured in
+// round 5, not part of the product build).
 #pragma once
 #include "common.h"
 
@@ -76,7 +76,7 @@ inline Plan plan_rows(int M, int BM, int tiles_n, int wg_per_round) {
     return best;
 }
 
-// ---- the four-wave form (gemm4.hip): 256 x 256 tiles, 4 waves x (128 x 128), K loop in assembly (kloop4.inc).
+// ---- lab builds (USPACE_FORM4): the four-wave form (tools/lab/gemm4/gemm4.hip): 256 x 256 tiles, 4 waves x (128 x 128), K loop in assembly.
 // us_gemm4_ok: can this launch take it (whole 256-column tiles, tile rows + strips, K tiles in pairs, at most two K slabs, 16-byte
 // bf16 rows, a flag combination it is instantiated for)?  us_gemm4_launch runs it (records the launch like the other forms).
 // own_plan: cut whatever M % 256 leaves into strips even where the round-count plan would spend a partly filled tile row (forced form)
