@@ -1,0 +1,68 @@
+"""`CNF.training_losses` for the reference's training scripts (train_lfm.py:154-183, train_lfm_t2i.py:190-204), host side only.
+
+This package implements the sampling hot path: forward kernels, no backward.  SURVEY.md 8(b) lets `training_losses` "delegate to
+a PyTorch fallback", and under the overlay the reference tree is on the path anyway -- so the loss is evaluated through the
+REFERENCE's own U-ViT (libs/uvit.py:182 / libs/uvit_t2i.py:192, loaded beside this package's module by `_overlay.load_shadowed`),
+built once per network over the SAME `nn.Parameter` objects as the MI355X module: the optimizer the script made from
+`nnet.parameters()`, its EMA copy and `state_dict()` all keep seeing one set of tensors, gradients land on them, and the next
+`decode()` repacks the updated weights (the module watches its parameters' versions).  Without the reference tree there is
+nothing to delegate to and the stub's error stands.
+
+Scope: single process.  (Under DDP the script's `accelerator.backward` relies on hooks armed by the wrapper's forward, which this
+path does not go through.)"""
+import torch
+
+
+def _cfg_of(net):
+    kw = dict(img_size=net.img_size, patch_size=net.patch_size, in_chans=net.in_chans, embed_dim=net.embed_dim, depth=net.depth,
+              num_heads=net.num_heads, mlp_ratio=net.hidden / net.embed_dim, qkv_bias=False, mlp_time_embed=False)
+    if type(net).__module__.endswith("uvit_t2i"):
+        kw.update(clip_dim=net.clip_dim, num_clip_token=net.num_clip_token)
+    else:
+        kw.update(num_classes=net.num_classes)
+    return kw
+
+
+def reference_twin(net, overlay):
+    """The reference's UViT over `net`'s own parameters, or None when the reference's module cannot be found."""
+    twin = net.__dict__.get("_reference_twin")
+    if twin is not None:
+        return twin
+    name = "libs.uvit_t2i" if type(net).__module__.endswith("uvit_t2i") else "libs.uvit"
+    try:
+        __import__("libs")
+        ref = overlay.load_shadowed(name, overlay.OVERLAY[name])
+    except ImportError:
+        ref = None
+    if ref is None or not hasattr(ref, "UViT"):
+        return None
+    with torch.random.fork_rng():            # the throw-away init draws random numbers: the script's RNG stream stays where it was
+        twin = ref.UViT(**_cfg_of(net))
+    own = dict(net.named_parameters())
+    theirs = [n for n, _ in twin.named_parameters()]
+    if set(theirs) != set(own):
+        raise RuntimeError(f"state_dict keys differ from the reference's: {sorted(set(theirs) ^ set(own))[:6]} ...")
+    for n in theirs:
+        mod = twin
+        *path, leaf = n.split(".")
+        for p in path:
+            mod = getattr(mod, p)
+        mod._parameters[leaf] = own[n]        # the SAME tensor: gradients and optimizer steps are shared
+    twin.train(net.training)
+    net.__dict__["_reference_twin"] = twin    # (not a submodule: parameters are not listed twice)
+    return twin
+
+
+def flow_matching_loss(velocity, x, sigma_min):
+    """flow_matching.py:88-100: x_t = t x + (1 - (1 - sigma) t) eps, target u = x - (1 - sigma) eps, mean squared error per sample.
+    Random draws in the reference's order (noise, then t)."""
+    noise = torch.randn_like(x)
+    t = torch.rand(len(x), device=x.device, dtype=x.dtype)
+    t_ = t[:, None, None, None]
+    x_new = t_ * x + (1 - (1 - sigma_min) * t_) * noise
+    u = x - (1 - sigma_min) * noise
+    return (velocity(t, x_new) - u).square().mean(dim=(1, 2, 3))
+
+
+def unwrap(net):
+    return net.module if hasattr(net, "module") and not hasattr(net, "embed_dim") else net

@@ -1,4 +1,29 @@
-"""`from flow_matching import CNF` of the reference (flow_matching.py:15) -> uspace_amd.flow_matching.CNF."""
-from uspace_amd.flow_matching import CNF, CNFBase  # noqa: F401
+"""`from flow_matching import CNF` of the reference (flow_matching.py:15) -> uspace_amd.flow_matching.CNF, with `training_losses`
+(flow_matching.py:88-100) delegated to the reference's own PyTorch U-ViT over this module's parameters (compat/_training.py)."""
+import os as _os
+import sys as _sys
+
+from uspace_amd.flow_matching import CNF as _CNF
+from uspace_amd.flow_matching import CNFBase  # noqa: F401
+
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+try:
+    import _overlay
+    import _training
+finally:
+    _sys.path.pop(0)
+
+
+class CNF(_CNF):
+    __module__ = _CNF.__module__          # the scripts (and their logs) see the class they asked for
+
+    def training_losses(self, x, y, sigma_min, **kwargs):
+        net = _training.unwrap(self.net)
+        twin = _training.reference_twin(net, _overlay)
+        if twin is None:
+            return super().training_losses(x, y, sigma_min, **kwargs)        # raises: nothing to delegate to
+        kwargs.setdefault("edit_loc", None)      # libs/uvit.py:313 reads it unconditionally
+        return _training.flow_matching_loss(lambda t, xt: twin(xt, t, y, **kwargs)[0], x, sigma_min)
+
 
 __all__ = ["CNF"]

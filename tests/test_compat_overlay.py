@@ -133,7 +133,115 @@ def test_against_the_real_reference_tree(tmp_path):
         assert type(net).__module__ == 'uspace_amd.libs.uvit', type(net).__module__
         assert CNF.__module__ == 'uspace_amd.flow_matching'
         assert hasattr(u, 'TrainState') and hasattr(u, 'sample2dir') and u.amortize(5, 2) == [2, 2, 1]
+        # ---- train_lfm.py:154-183 / train_lfm_t2i.py:190-204: `score_model.training_losses(...)`, `.mean().backward()`, on CPU.
+        # The loss is the reference's own forward (libs/uvit.py:306-351) over THIS module's parameters (compat/_training.py).
+        import torch
+        torch.manual_seed(3)
+        score = CNF(net=net)
+        x = torch.randn(3, 4, 32, 32)
+        torch.manual_seed(11)
+        loss = score.training_losses(x, y=None, sigma_min=1e-4)
+        assert loss.shape == (3,) and bool(torch.isfinite(loss).all())
+        loss.mean().backward()
+        grads = {n: p.grad for n, p in net.named_parameters()}
+        assert all(g is not None for g in grads.values()) and sum(float(g.abs().sum()) for g in grads.values()) > 0
+        # the same numbers as the reference computes by itself: its own UViT with this state_dict, its formula (flow_matching.py:88-100)
+        import libs._ref_uvit as R
+        ref = R.UViT(img_size=32, patch_size=2, in_chans=4, embed_dim=64, depth=2, num_heads=1)
+        ref.load_state_dict(net.state_dict(), strict=True)
+        torch.manual_seed(11)
+        noise = torch.randn_like(x); t = torch.rand(len(x)); t_ = t[:, None, None, None]
+        want = ((ref(t_ * x + (1 - (1 - 1e-4) * t_) * noise, t, None, edit_loc=None)[0] - (x - (1 - 1e-4) * noise)).square().mean(dim=(1, 2, 3)))
+        assert torch.equal(loss.detach(), want.detach()), (loss, want)
+        # an optimizer step on nnet.parameters() is seen by the twin (one set of tensors), and nothing is listed twice
+        assert len(list(net.parameters())) == len(net.state_dict())
+        opt = torch.optim.SGD(net.parameters(), lr=0.1)
+        opt.step()
+        torch.manual_seed(11)
+        loss2 = score.training_losses(x, y=None, sigma_min=1e-4)
+        assert not torch.equal(loss2.detach(), loss.detach())
+        # T2I twin
+        from flow_matching_t2i import CNF as CNF_T
+        net_t = u.get_nnet('uvit_t2i', img_size=32, patch_size=2, in_chans=4, embed_dim=64, depth=2, num_heads=1, clip_dim=64, num_clip_token=5)
+        lt = CNF_T(net=net_t).training_losses(x, context=torch.randn(3, 5, 64), sigma_min=1e-4)
+        lt.mean().backward()
+        assert lt.shape == (3,) and net_t.context_embed.weight.grad is not None
         print('ok')
     """ % (ROOT, COMPAT, ROOT))
     out = run([sys.executable, "-c", code], str(tmp_path), {"PYTHONDONTWRITEBYTECODE": "1"})
     assert out.strip().endswith("ok")
+
+
+EVAL_SCRIPT = """
+# the eval path of train_lfm_t2i.py:210-253 in miniature: sample_fn -> score_model.decode(noise, context=..., **config.dissection)
+# with dissect_name=None (=> the reference's default sampler, adaptive dopri5 1e-5, flow_matching_t2i.py:77-83) -> sample2dir
+import json, os, sys, tempfile
+import numpy as np, torch
+sys.path.insert(0, %(root)r)
+from tests.test_multigpu_readiness import _FakeKernels
+from uspace_amd import _hip
+class Fake(_FakeKernels):
+    def uspace_ode_error_norm(self, y0, y1, ks, coefs, n, rtol, atol, numel, scratch, result, stream):
+        a0, a1 = self._arr(y0, numel), self._arr(y1, numel)
+        e = np.zeros(numel, np.float32)
+        for i in range(n):
+            e += np.float32(coefs[i]) * self._arr(ks[i], numel)
+        r = e / (atol + rtol * np.maximum(np.abs(a0), np.abs(a1)))
+        out = self._arr(result, 2)
+        out[1] = float((r.astype(np.float64) ** 2).sum()); out[0] = float(np.sqrt(out[1] / numel))
+        return 0
+fake = Fake(_hip.lib())
+_hip.lib = lambda: fake
+_hip.require_device = lambda t, name="tensor": None
+_hip.stream_ptr = lambda: None
+_hip.sync_current_stream = lambda: None
+from flow_matching_t2i import CNF
+from tools.utils_uvit import get_nnet, sample2dir
+class Acc:
+    is_main_process, num_processes = True, 1
+    def gather(self, t): return t
+net = get_nnet("uvit_t2i", img_size=32, patch_size=2, in_chans=4, embed_dim=64, depth=2, num_heads=1, clip_dim=64, num_clip_token=5)
+score_model = CNF(net=net)
+dissection = dict(dissect_name=None, edit_loc=None, solver_kwargs=dict(solver="adaptive", solver_adaptive="dopri5"))
+def sample_fn(n):
+    z = score_model.decode(torch.randn(n, 4, 32, 32), context=torch.randn(n, 5, 64), **dissection)
+    return z[:, :3]
+with tempfile.TemporaryDirectory() as d:
+    sample2dir(Acc(), d, 5, 2, sample_fn, unpreprocess_fn=lambda v: v)
+    saved = sorted(os.listdir(d))
+st = score_model.last_stats
+try:
+    score_model.training_losses(torch.randn(2, 4, 32, 32), context=torch.randn(2, 5, 64), sigma_min=1e-4)
+    tl = "no error"
+except NotImplementedError as e:
+    tl = "NotImplementedError"
+print(json.dumps(dict(saved=saved, nfe=st.nfe, accepted=st.accepted, forwards=fake.forwards, cnf=CNF.__module__, tl=tl)))
+"""
+
+
+def test_eval_path_of_the_training_script_on_a_fake_tree(tmp_path):
+    """`train_lfm_t2i.py`'s evaluation (its only use of this package besides the loss): `sample2dir` -> `sample_fn` -> `decode` with
+    `dissect_name=None`, i.e. adaptive Dormand-Prince, through the overlay's import names; kernels stubbed at `_hip.lib()` (v = -x: the
+    exact solution e^-1 z is reached with few accepted steps).  The loss itself has nothing to delegate to here -- the fake tree's
+    U-ViT refuses to import -- and says so."""
+    make_fake_reference(str(tmp_path))
+    with open(tmp_path / "tools" / "utils_uvit.py", "a") as f:
+        f.write(textwrap.dedent("""
+            import os
+            def sample2dir(accelerator, path, n_samples, mini_batch_size, sample_fn, unpreprocess_fn=None):
+                os.makedirs(path, exist_ok=True)
+                idx, bs = 0, mini_batch_size * accelerator.num_processes
+                k, r = divmod(n_samples, bs)
+                for b in k * [bs] + ([r] if r else []):
+                    samples = accelerator.gather(unpreprocess_fn(sample_fn(mini_batch_size)).contiguous())[:b]
+                    for s in samples:
+                        open(os.path.join(path, f"{idx}.png"), "w").write(str(tuple(s.shape)))
+                        idx += 1
+        """))
+    with open(tmp_path / "train_fake.py", "w") as f:
+        f.write(EVAL_SCRIPT % dict(root=ROOT))
+    out = run([sys.executable, "train_fake.py"], str(tmp_path), {"PYTHONPATH": COMPAT + os.pathsep + ROOT})
+    r = json.loads(out.strip().splitlines()[-1])
+    assert r["saved"] == [f"{i}.png" for i in range(5)] and r["cnf"] == "uspace_amd.flow_matching_t2i"
+    assert r["accepted"] >= 1 and r["nfe"] >= 2 + 6 * r["accepted"] and r["forwards"] >= 3 * r["nfe"] - 12
+    assert r["tl"] == "NotImplementedError"

@@ -189,6 +189,28 @@ def test_attention_several_heads_per_workgroup_is_bit_equal_to_one(hip, B, L, H)
         assert rel_l2(whole[b * L:(b + 1) * L].float().cpu().numpy().reshape(1, L, H * 64), ref) < 6e-3
 
 
+@pytest.mark.parametrize("B,L,H", [(64, 334, 16), (40, 257, 16)])
+def test_attention_ignores_what_lies_behind_the_tensor(hip, B, L, H):
+    """The padded key / value rows (L .. 16 * tiles) of the LAST batch element lie behind the caller's tensor.  Their P is 0, but 0 x NaN
+    is NaN in the P.V product: whatever the kernel reads there must be finite by construction (LDS-DMA path: row L - 1 repeated;
+    several-heads-per-workgroup path: out of the buffer descriptor's range, zeros), not by luck.  qkv is a view of a larger buffer whose
+    tail holds NaN / Inf bf16 patterns; the result must equal the run on a tensor with an ordinary tail, bit for bit."""
+    rng = np.random.default_rng(B + L + H)
+    n = B * L * 3 * H * 64
+    vals = torch.from_numpy(bf16_round(_rand(rng, n, scale=1.5))).to(torch.bfloat16)
+    tail = 64 * 3 * H * 64                                       # far more rows than any tile padding reaches
+    outs = []
+    for poison in (False, True):
+        big = torch.zeros(n + tail, dtype=torch.bfloat16, device="cuda")
+        big[:n] = vals.cuda()
+        if poison:
+            pat = torch.from_numpy(np.array([0x7FC0, 0x7F80, 0xFF80, 0x7FFF], dtype=np.uint16).view(np.int16))   # NaN, +Inf, -Inf, NaN
+            big[n:] = pat.repeat(tail // 4).view(torch.bfloat16).cuda()
+        outs.append(hip.attention(big[:n].view(B * L, 3 * H * 64), B, L, H))
+    assert bool(torch.isfinite(outs[1].float()).all())
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_attention_spiked_row_softmax_is_stable(hip):
     # one key dominates one query by a large margin: exp underflow elsewhere must not produce NaN
     rng = np.random.default_rng(3)

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64 * NW, NW == 6 ? 3 : (W4 ? 4 : 2)) void attention
     const int L = LC > 0 ? LC : L_rt;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NP = (NT + 1) / 2;       // 32-key steps of the P.V product
-    constexpr int VROWS = NP * 32;         // V rows staged (rows >= L repeat row L-1: finite, their P is 0)
+    constexpr int VROWS = NP * 32;         // V rows staged (rows >= L: row L-1 again on the LDS-DMA path, zeros on the register path of HPW > 1 -- finite, their P is 0)
     constexpr int KROWS = NT * 16;
     char* sK = smem;                                   // [KROWS][64] bf16, 16-B chunks swizzled (k_off)
     char* sV = smem + KROWS * KROW_BYTES;              // [VROWS][64] bf16, 32-B chunks swizzled (v_off)
@@ -202,9 +202,10 @@ __global__ __launch_bounds__(64 * NW, NW == 6 ? 3 : (W4 ? 4 : 2)) void attention
     const bf16_t* nv = nbase + (2 * H + (pf_on ? bh_next % H : h)) * DH;
     // piece i of this lane: 16 bytes of row (c * 8 + lane / 8) of K (c < KROWS / 8) or V, the chunk the LDS image wants at position
     // lane % 8.  Buffer loads: the lane's part of the address (row within the block, swizzled chunk -- the swizzle keys (r >> 1) & 7
-    // and (r >> 1) & 3 see only the block's parity, which is the wave's) is ONE 32-bit offset per operand, the block's rows go into the
-    // scalar offset; rows >= L are out of the descriptor's range and read as zeros (the LDS-DMA path repeats row L - 1 there: their
-    // scores are masked and their P is 0 either way).
+    // and (r >> 1) & 3 see only the block's parity, which is the wave's) is one 32-bit offset per operand; the block's rows are ADDED to
+    // it (one VALU add per load) rather than passed as the scalar offset: the hardware's range check covers the vector offset only, and
+    // rows >= L must really be out of range -- they then read as zeros, where the LDS-DMA path repeats row L - 1; either way finite:
+    // their scores are masked and their P is 0, but 0 x NaN from whatever lies behind the tensor would poison P.V.
     const uint32_t row_b = (uint32_t)C3 * 2u;
     const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)nk, 0, (int)((uint32_t)(L - 1) * row_b + 128u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)nv, 0, (int)((uint32_t)(L - 1) * row_b + 128u), 0x00020000);
@@ -215,8 +216,8 @@ __global__ __launch_bounds__(64 * NW, NW == 6 ? 3 : (W4 ? 4 : 2)) void attention
     auto pf_load = [&](int i) {
         const int c = i * NW + wave;
         pf_u4 v = {0u, 0u, 0u, 0u};
-        if (c < KROWS / 8) v = __builtin_amdgcn_raw_buffer_load_b128(rs_k, voff_k, (uint32_t)(c * 8) * row_b, 0);
-        else if (c < PF_BLOCKS) v = __builtin_amdgcn_raw_buffer_load_b128(rs_v, voff_v, (uint32_t)((c - KROWS / 8) * 8) * row_b, 0);
+        if (c < KROWS / 8) v = __builtin_amdgcn_raw_buffer_load_b128(rs_k, voff_k + (uint32_t)(c * 8) * row_b, 0, 0);
+        else if (c < PF_BLOCKS) v = __builtin_amdgcn_raw_buffer_load_b128(rs_v, voff_v + (uint32_t)((c - KROWS / 8) * 8) * row_b, 0, 0);
         pf[i] = make_uint4(v[0], v[1], v[2], v[3]);
     };
     int pf_it = 0;
@@ -393,11 +394,11 @@ __global__ __launch_bounds__(64 * NW, NW == 6 ? 3 : (W4 ? 4 : 2)) void attention
                 const bool more = (u + 1 < NP) && (2 * (u + 1) <= t_last);
                 if (more) load_v(u + 1, vb[(u + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
-        #pragma unroll
+#pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb[u & 1][dt].v, pb[u & 1].v, o[dt], 0, 0, 0);
                 osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, SCALED ? pu[u & 1].v : pb[u & 1].v, osum, 0, 0, 0);
-                        if (more) make_p(u + 1);
+                if (more) make_p(u + 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
