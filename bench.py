@@ -387,7 +387,7 @@ def main():
         D, Hd = cfg["embed_dim"], 4 * cfg["embed_dim"]
         fold = _hip.lib().uspace_uvit_get_ln_fold() != 0       # norm2 folded into fc1 (default) or a separate launch
         fc1_flags = _hip.EPI_BIAS | _hip.EPI_GELU | _hip.EPI_OUT_BF16 | (_hip.EPI_LN_IN if fold else 0)
-        recs, peaks = [], None
+        recs, peaks, gemm_op = [], None, None
         if rank == 0 and not args.no_extra:
             was = net.use_graph
             net.use_graph = False
@@ -402,6 +402,7 @@ def main():
                 raise SystemExit(f"bench.py: the launch recorder was full ({rec_cap} launches) and dropped {rec_dropped}: roofline would cover a truncated solve")
             net.use_graph = was
             peaks = _hip.prof_peaks()
+            gemm_op = _hip.prof_mfma_gemm_op()
         if world > 1:
             dist.barrier()
 
@@ -487,7 +488,11 @@ def main():
                 if peaks:
                     line["roofline"]["peak_measured"] = {
                         "mfma_bf16_tflops": peaks[0], "hbm_copy_gbs": peaks[1], "shader_ghz_under_mfma_loop": peaks[2],
+                        "mfma_bf16_tflops_instruction": "v_mfma_f32_32x32x16_bf16, near-constant operands (burst figure)",
                         "frac_of_measured_mfma": r["tflops"] / peaks[0],
+                        "gemm_instruction": {
+                            "instruction": "v_mfma_f32_16x16x32_bf16 (the GEMM's), pseudo-random operands in [-1, 1)",
+                            "tflops": gemm_op[0], "shader_ghz": gemm_op[1], "frac_of_it": r["tflops"] / gemm_op[0]} if gemm_op else None,
                         "loop": "20000 iterations x 32 v_mfma_f32_32x32x16_bf16 per wave, 1024 waves (one per SIMD), about 10 ms: long enough for the "
                                 "clock to settle at its sustained value (the guide's 2495 TFLOP/s is a short burst at 2.4 GHz)",
                         "how": "v_mfma_f32_32x32x16_bf16-only loop, one wave on every SIMD; the chip clocks to its power budget, so the "

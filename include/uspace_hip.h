@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define USPACE_ABI_VERSION 9
+#define USPACE_ABI_VERSION 10
 
 #define USPACE_OK 0
 #define USPACE_ERR_ARG (-1)         /* bad pointer / size / unsupported shape */
@@ -393,6 +393,10 @@ USPACE_API long uspace_prof_dropped(void);
 USPACE_API int uspace_prof_mfma_peak(int iters, double* tflops);
 /* ... and the shader clock the chip sustained under that load (GHz; s_memtime ticks of one workgroup / wall time) */
 USPACE_API int uspace_prof_mfma_peak_clock(int iters, double* tflops, double* shader_ghz);
+/* The two above loop over v_mfma_f32_32x32x16_bf16 on near-constant operands: the burst figure.  This one runs the GEMM's own
+ * instruction, v_mfma_f32_16x16x32_bf16, on pseudo-random operands in [-1, 1): what the matrix pipe sustains on data that toggles
+ * like real activations (the chip is power-limited there; ABI 10). */
+USPACE_API int uspace_prof_mfma_peak_gemm_op(int iters, double* tflops, double* shader_ghz);
 USPACE_API int uspace_prof_hbm_copy(size_t bytes, int reps, double* gb_per_s);
 
 #ifdef __cplusplus

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     from uspace_amd import _hip
     assert set(_hip.SIGNATURES) == declared
-    assert _hip.lib().uspace_abi_version() == _hip.ABI_VERSION == 9
+    assert _hip.lib().uspace_abi_version() == _hip.ABI_VERSION == 10
 
 
 def test_struct_layouts_agree_between_header_binding_and_integration_doc():

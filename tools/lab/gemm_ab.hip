@@ -1,5 +1,7 @@
 // Interleaved A/B timing of two builds of libuspace_hip.so on the U-ViT GEMM shapes (run on the GPU box):
-//   tools/lab/_build/gemm_ab <libA.so> <libB.so> [M] [rounds] [reps] [D] [formA] [formB]
+//   tools/lab/_build/gemm_ab <libA.so> <libB.so> [M] [rounds] [reps] [D] [formA] [formB] [tileA] [tileB]
+// tileA / tileB (round 5): uspace_lab_gemm_force_tile of each library (lab builds: -1 = the planner's choice, 0 = 256x256, 1 = 192x256, 2 = 128x128,
+// 4 = 256x128, 5 = 64x64)
 // formA / formB (round 5): uspace_gemm_set_big_form of each library (0 = four-wave form where it applies, 1 = 8-wave only); to compare the
 // two forms of ONE build pass a copy of the library as libB (the same path would be the same loaded object and share the switch)
 // Both libraries run the same launches alternately inside one process (box-to-box and thermal drift is larger than
@@ -72,7 +74,13 @@ int main(int argc, char** argv) {
         if (argc > 7 + v) {
             typedef int (*form_fn)(int);
             form_fn f = (form_fn)dlsym(L[v].h, "uspace_gemm_set_big_form");
-            if (!f || f(atoi(argv[7 + v])) < 0) { fprintf(stderr, "library %d: no form switch / bad form\n", v); return 2; }
+            if (atoi(argv[7 + v]) >= 0 && (!f || f(atoi(argv[7 + v])) < 0)) { fprintf(stderr, "library %d: no form switch / bad form\n", v); return 2; }
+        }
+        if (argc > 9 + v) {
+            typedef void (*tile_fn)(int);
+            tile_fn f = (tile_fn)dlsym(L[v].h, "uspace_lab_gemm_force_tile");
+            if (atoi(argv[9 + v]) >= 0 && !f) { fprintf(stderr, "library %d: not a lab build (no uspace_lab_gemm_force_tile)\n", v); return 2; }
+            if (f) f(atoi(argv[9 + v]));
         }
     }
     constexpr int B_ = USPACE_EPI_BIAS, G_ = USPACE_EPI_GELU, R_ = USPACE_EPI_RESIDUAL, F_ = USPACE_EPI_OUT_F32, H_ = USPACE_EPI_OUT_BF16, C_ = USPACE_EPI_CEN_OUT,

@@ -1,4 +1,7 @@
-"""Lab: cycle stamps around the K-loop barriers of the 256x256 GEMM (library built with -DUSPACE_KTRACE=1):
+"""Lab: cycle stamps around the K-loop barriers of the 256x256 GEMM.  The stamps (K_STAMP / K_PHASE, switch USPACE_KTRACE) left the product
+source in round 5: re-apply them to a scratch copy first --
+   patch -o /tmp/gemm_ktrace.hip uspace_amd/csrc/gemm.hip tools/lab/dropped/gemm_ktrace_fulllines_r04.patch
+and build that copy with -DUSPACE_LAB=1 -DUSPACE_KTRACE=1 the way tools/lab/build_variant.sh builds gemm.hip -- then
    python tools/lab/gemm_trace.py tools/lab/_build/lib_ktrace.so [N K]
 fc1-shaped launch (M = 64*257, +bias +GELU -> bf16) by default.  Workgroups 10 (first round of tiles) and 600 (third), every wave:
 slot 0 kernel start, 1 first tile visible, 2+2kt / 3+2kt before / after the barrier that ends K tile kt, 62 K loop done, 63 kernel end."""

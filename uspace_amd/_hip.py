@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("USPACE_HIP_LIB") or os.path.join(_HERE, "libuspace_hi
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_OUT_BF16 = 1, 2, 4, 8, 16
 EPI_CEN_OUT, EPI_LN_IN, EPI_RANK1 = 32, 64, 128          # uspace_gemm_bf16_ext only (LayerNorm folded through the GEMMs)
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _ERR = {-1: "USPACE_ERR_ARG", -2: "USPACE_ERR_LAUNCH", -3: "USPACE_ERR_WORKSPACE"}
 
@@ -124,6 +124,7 @@ SIGNATURES = {
     "uspace_prof_dropped": (_L, []),
     "uspace_prof_mfma_peak": (_I, [_I, ctypes.POINTER(ctypes.c_double)]),
     "uspace_prof_mfma_peak_clock": (_I, [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "uspace_prof_mfma_peak_gemm_op": (_I, [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "uspace_prof_hbm_copy": (_I, [_SZ, _I, ctypes.POINTER(ctypes.c_double)]),
 }
 
@@ -303,6 +304,14 @@ def prof_peaks(mfma_iters=20000, copy_bytes=1 << 30, copy_reps=10):
     check(lib().uspace_prof_mfma_peak_clock(mfma_iters, ctypes.byref(tf), ctypes.byref(ghz)), "uspace_prof_mfma_peak_clock")
     check(lib().uspace_prof_hbm_copy(copy_bytes, copy_reps, ctypes.byref(gb)), "uspace_prof_hbm_copy")
     return tf.value, gb.value, ghz.value
+
+
+def prof_mfma_gemm_op(mfma_iters=20000):
+    """(TFLOP/s, sustained shader GHz) of a v_mfma_f32_16x16x32_bf16-only loop on pseudo-random operands: the GEMM's instruction on
+    data that toggles like real activations (prof_peaks() times v_mfma_f32_32x32x16_bf16 on near-constant operands)."""
+    tf, ghz = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    check(lib().uspace_prof_mfma_peak_gemm_op(mfma_iters, ctypes.byref(tf), ctypes.byref(ghz)), "uspace_prof_mfma_peak_gemm_op")
+    return tf.value, ghz.value
 
 
 def prof_all_begin(max_launches=16384):

@@ -36,7 +36,7 @@ using namespace usgemm;
 #if !USPACE_LAB
 #if defined(USPACE_ABLATE_NOSTORE) || defined(USPACE_ABLATE_NOEPI) || defined(USPACE_ABLATE_NOGELU) || defined(USPACE_DMA_FLAT) || \
     defined(USPACE_RING_PREFETCH_ALL) || defined(USPACE_TINY_UNROLL) || defined(USPACE_EARLY_BARRIER) || defined(USPACE_TALL_COST) || defined(USPACE_CHAIN) || \
-    defined(USPACE_CHAIN_ABL) || defined(USPACE_CHAIN_DMA8) || defined(USPACE_CHAIN_SPLIT) || defined(USPACE_CHAIN_BODY) || defined(USPACE_FULL_LINES) || defined(USPACE_KTRACE) || defined(USPACE_MMA_ORDER) || defined(USPACE_FORM4)
+    defined(USPACE_CHAIN_ABL) || defined(USPACE_CHAIN_DMA8) || defined(USPACE_CHAIN_SPLIT) || defined(USPACE_CHAIN_BODY) || defined(USPACE_MMA_ORDER) || defined(USPACE_FORM4) || defined(USPACE_SAME_PANELS)
 #error "measurement switches need -DUSPACE_LAB=1 (tools/lab/build_variant.sh); the product build takes none"
 #endif
 #define USPACE_ABLATE_NOSTORE 0
@@ -71,53 +71,16 @@ using namespace usgemm;
 // columns inner (rounds 1-4), 2 = columns outer.  0 and 2 are lab settings.
 #define USPACE_MMA_ORDER 1
 #endif
-#ifndef USPACE_KTRACE
-#define USPACE_KTRACE 0          // 1: cycle stamps (s_memtime) around the K loop's barriers of two workgroups, read with uspace_lab_gemm_trace (tools/lab/gemm_trace.py)
-#endif
-#ifndef USPACE_FULL_LINES
-#define USPACE_FULL_LINES 0      // bit mask: 1 = bf16 outputs, 2 = fp32 output of interior tiles as 8 rows x 128 B per store instruction (A/B measurements)
+#ifndef USPACE_SAME_PANELS
+// (lab, wrong results, timing only -- VERDICT r4 task 3: what is the fabric traffic of the operand panels worth?) bit 0: every workgroup of an XCD
+// stages the SAME 256 activation rows, bit 1: the same 256 weight rows: after first touch its operands come from its L2, nothing through the fabric
+#define USPACE_SAME_PANELS 0
 #endif
 #ifndef USPACE_FORM4
 #define USPACE_FORM4 0           // 1: 256x256 launches may take the four-wave form of tools/lab/gemm4/ (round 5; lab builds link gemm4.o)
 #endif
 #ifndef USPACE_CHAIN
 #define USPACE_CHAIN 0           // 1: multi-round store-only launches of 256x256 tiles take the chain form (gemm_chain.h)
-#endif
-#if USPACE_KTRACE
-// 2 workgroups x 8 waves x 64 stamps (low 32 bits of s_memtime), kept in one VGPR per wave (lane = slot) until the kernel's end
-__device__ uint32_t g_gemm_trace[2 * 8 * 64];
-#define K_STAMP(slot)                                                                      \
-    if (ktr_on) {                                                                          \
-        unsigned long long t_;                                                             \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
-        ktr = lane == ((slot) & 63) ? (uint32_t)t_ : ktr;                                  \
-    }
-// phase stamps inside a K tile: s_memtime without a wait (a wait would serialise the fragment prefetch); the three values are parked in
-// SGPRs and copied into lanes 32 + 3 (kt - 4) + i at the tile's barrier stamp, K tiles 4..11.  (The outstanding SMEM result shifts the
-// compiler's counted lgkmcnt waits by one: a fragment may be consumed a few cycles early -- results of this build are not to be trusted.)
-#define K_PHASE(i) asm volatile("s_memtime %0" : "=s"(ktph[i]));
-#define K_PHASE_FLUSH(kt)                                                                  \
-    if (ktr_on && (kt) >= 4 && (kt) < 12) {                                                \
-        _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_)                                   \
-            ktr = lane == 32 + 3 * ((kt) - 4) + i_ ? (uint32_t)ktph[i_] : ktr;             \
-    }
-// USPACE_KTRACE == 2: instead of the phase stamps, the wait for this wave's own LDS-DMA in front of the barrier is stamped separately (slot 32 + kt)
-#if USPACE_KTRACE == 2
-#undef K_PHASE
-#undef K_PHASE_FLUSH
-#define K_PHASE(i)
-#define K_PHASE_FLUSH(kt)
-#define K_VMWAIT(kt)                                                                       \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
-    K_STAMP(32 + (kt))
-#else
-#define K_VMWAIT(kt)
-#endif
-#else
-#define K_STAMP(slot)
-#define K_PHASE(i)
-#define K_PHASE_FLUSH(kt)
-#define K_VMWAIT(kt)
 #endif
 constexpr int ROW_BYTES = 128;
 
@@ -159,19 +122,6 @@ __device__ __forceinline__ uint4 widen_pair(uint2 a, uint2 b) {
     const auto ry = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
     return make_uint4(rx[0], ry[0], rx[1], ry[1]);
 }
-
-// Two 16-byte vectors per lane, each laid out as 16 rows (lane % 16) x 64 contiguous bytes (the left and the right half of 128-byte
-// row segments) -> lo: rows 0-7 with all 128 bytes (lanes 8-15 of each 16-lane group take the right half of row lane - 8),
-// hi: rows 8-15.  One DPP move (row_ror:8, half of the banks) per dword: a store instruction then writes 8 whole cache lines.
-typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-__device__ __forceinline__ void line_pair(const u32x4& l, const u32x4& r, u32x4& lo, u32x4& hi) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        lo[c] = (uint32_t)__builtin_amdgcn_update_dpp((int)l[c], (int)r[c], 0x128, 0xf, 0xc, false);
-        hi[c] = (uint32_t)__builtin_amdgcn_update_dpp((int)r[c], (int)l[c], 0x128, 0xf, 0x3, false);
-    }
-}
-__device__ __forceinline__ u32x4 as_u32x4(const uint4& v) { return (u32x4){v.x, v.y, v.z, v.w}; }
 
 // byte offset inside a [rows][64] bf16 LDS tile of 16-B chunk `c` of row `r` (swizzled)
 __device__ __forceinline__ int lds_off(int r, int c) { return r * ROW_BYTES + ((c ^ ((r >> 1) & 7)) << 4); }
@@ -235,13 +185,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN;
     const int wn = wave % WN;
-#if USPACE_KTRACE
-    const int ktr_blk = blockIdx.x == 10 ? 0 : (blockIdx.x == 600 ? 1 : -1);
-    const bool ktr_on = ktr_blk >= 0 && NST == 2 && BM == 256 && BN == 256;
-    uint32_t ktr = 0;
-    unsigned long long ktph[3] = {0, 0, 0};
-    K_STAMP(0)
-#endif
 
     // ---- XCD-aware tile id.  Block b runs on XCD b%8 (observed; speed only).  When the grid splits into
     //      super-tiles of 8 x 4 tiles (one round of an XCD's 32 CUs) each XCD walks whole super-tiles, so
@@ -288,7 +231,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
     for (int i = 0; i < ISSUES_A; ++i) {
         const int r = i * ROWS_PER_ISSUE + srow;
         const int c = schunk ^ ((r >> 1) & 7);
-        int m = m0 + r;
+        int m = ((USPACE_SAME_PANELS & 1) ? (int)(blockIdx.x & 7) * BM : m0) + r;
         m = m < m_lim ? m : m_lim - 1;
         a_off[i] = (uint32_t)(m * g.lda + c * 8) * 2u;
     }
@@ -296,7 +239,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
     for (int i = 0; i < ISSUES_W; ++i) {
         const int r = i * ROWS_PER_ISSUE + srow;
         const int c = schunk ^ ((r >> 1) & 7);
-        int n = n0 + r;
+        int n = ((USPACE_SAME_PANELS & 2) ? (int)(blockIdx.x & 7) * BN : n0) + r;
         n = n < g.N ? n : g.N - 1;
         w_off[i] = (uint32_t)(n * g.ldw + c * 8) * 2u;
     }
@@ -518,7 +461,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         if constexpr (ROWV) fetch_rowv();
         if constexpr (EARLY_EPI) load_epi_consts();
         __syncthreads();
-        K_STAMP(1)
     }
     if constexpr (ROWV) {
         if (tid < BM + 16) {
@@ -568,7 +510,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         __builtin_amdgcn_sched_barrier(0);                                                         \
         MMA(af0, wf0, 0, 1, HM)                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        K_PHASE(0)                                                                                 \
         MMA(af1, wf0, 1, 0, 1)                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         LOAD_A(af0, cur, 0, c_k1)                                                                  \
@@ -577,7 +518,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         __builtin_amdgcn_sched_barrier(0);                                                         \
         MMA(af1, wf0, 1, 1, HM)                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        K_PHASE(1)                                                                                 \
         MMA(af0, wf1, 0, 0, 1)                                                                     \
         MMA_X(xf1, wf1)                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                         \
@@ -585,15 +525,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         __builtin_amdgcn_sched_barrier(0);                                                         \
         MMA(af0, wf1, 0, 1, HM)                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        K_PHASE(2)                                                                                 \
         if constexpr (!EARLYB) { MMA(af1, wf1, 1, 0, HM / 2) }                                     \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         if (MORE) {                                                                                \
-            K_STAMP(2 + 2 * (kt))                                                                  \
-            K_PHASE_FLUSH(kt)                                                                      \
-            K_VMWAIT(kt)                                                                           \
             __syncthreads(); /* tile kt+1 landed for everyone; buffer kt&1 is free */              \
-            K_STAMP(3 + 2 * (kt))                                                                  \
             if (MORE2) stage_a(kt + 2, kt & 1, X_ON);                                                  \
             const char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;                                 \
             LOAD_A(af0, nxt, 0, c_k0)                                                              \
@@ -801,7 +736,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
 #undef MMA
 #undef MMA_X
 
-    K_STAMP(62)
     // ---- epilogue: lane holds, for sub-tile (i,j), row m = ..+fr and columns n = ..+4*fq+{0,1,2,3}
     if constexpr (!EARLY_EPI) load_epi_consts();
     float ps1 = 0.f, ps2 = 0.f;   // producer: running partial sums of the row being emitted
@@ -910,7 +844,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         return;
     }
 #endif
-    constexpr bool FL_BF = (USPACE_FULL_LINES & 1) != 0 && TN == 4, FL_F32 = (USPACE_FULL_LINES & 2) != 0 && TN == 4;
     if (interior && g.wide) {
         const int nw = n0 + wn * (BN / WN) + (fq & 1) * 16 + (fq >> 1) * 8;   // this lane's column in a widened pair (+ 32 per pair)
 #pragma unroll
@@ -928,16 +861,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
             f32x4 s1v = {0.f, 0.f, 0.f, 0.f}, s2v = {0.f, 0.f, 0.f, 0.f};   // CEN: the row's sums as packed vector accumulators
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                if constexpr ((FLAGS & USPACE_EPI_OUT_F32) != 0 && !FL_F32) *(f32x4*)(out_f32 + (size_t)m * g.ld_f32 + n0 + wn * (BN / WN) + j * 16 + fq * 4) = v[j];
-                if constexpr ((FLAGS & USPACE_EPI_OUT_F32) != 0 && FL_F32) {
-                    if (j & 1) {
-                        u32x4 lo, hi;
-                        line_pair(__builtin_bit_cast(u32x4, v[j - 1]), __builtin_bit_cast(u32x4, v[j]), lo, hi);
-                        float* po = out_f32 + (size_t)(m0 + wm * (BM / WM) + i * 16 + (fr & 7)) * g.ld_f32 + n0 + wn * (BN / WN) + (j - 1 + (fr >> 3)) * 16 + fq * 4;
-                        *(u32x4*)po = lo;
-                        *(u32x4*)(po + 8 * (size_t)g.ld_f32) = hi;
-                    }
-                }
+                if constexpr ((FLAGS & USPACE_EPI_OUT_F32) != 0) *(f32x4*)(out_f32 + (size_t)m * g.ld_f32 + n0 + wn * (BN / WN) + j * 16 + fq * 4) = v[j];
                 if constexpr (FLAGS & USPACE_EPI_OUT_BF16) {
                     pk[j].x = pack_bf2(v[j][0], v[j][1]);
                     pk[j].y = pack_bf2(v[j][2], v[j][3]);
@@ -955,28 +879,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
                 ps2 = (s2v[0] + s2v[1]) + (s2v[2] + s2v[3]);
             }
 #if !USPACE_ABLATE_NOSTORE
-            if constexpr (FL_BF) {
-                // whole 128-byte lines: rows 0-7 of the sub-tile row in one store instruction, rows 8-15 in the next
-                const size_t mr = (size_t)(m0 + wm * (BM / WM) + i * 16 + (fr & 7));
-                const int nl = n0 + wn * (BN / WN) + (fr >> 3) * 32 + (fq & 1) * 16 + (fq >> 1) * 8;
-                if constexpr (FLAGS & USPACE_EPI_OUT_BF16) {
-                    u32x4 lo, hi;
-                    line_pair(as_u32x4(widen_pair(pk[0], pk[1])), as_u32x4(widen_pair(pk[2], pk[3])), lo, hi);
-                    *(u32x4*)(g.out_bf16 + mr * g.ld_bf16 + nl) = lo;
-                    *(u32x4*)(g.out_bf16 + (mr + 8) * g.ld_bf16 + nl) = hi;
-                }
-                if constexpr (CEN) {
-                    u32x4 lo, hi;
-                    line_pair(as_u32x4(widen_pair(pc[0], pc[1])), as_u32x4(widen_pair(pc[2], pc[3])), lo, hi);
-                    *(u32x4*)(g.out_cen + mr * g.ld_cen + nl) = lo;
-                    *(u32x4*)(g.out_cen + (mr + 8) * g.ld_cen + nl) = hi;
-                }
-            } else {
 #pragma unroll
-                for (int j = 0; j < TN; j += 2) {
-                    if constexpr (FLAGS & USPACE_EPI_OUT_BF16) *(uint4*)(g.out_bf16 + (size_t)m * g.ld_bf16 + nw + j * 16) = widen_pair(pk[j], pk[j + 1]);
-                    if constexpr (CEN) *(uint4*)(g.out_cen + (size_t)m * g.ld_cen + nw + j * 16) = widen_pair(pc[j], pc[j + 1]);
-                }
+            for (int j = 0; j < TN; j += 2) {
+                if constexpr (FLAGS & USPACE_EPI_OUT_BF16) *(uint4*)(g.out_bf16 + (size_t)m * g.ld_bf16 + nw + j * 16) = widen_pair(pk[j], pk[j + 1]);
+                if constexpr (CEN) *(uint4*)(g.out_cen + (size_t)m * g.ld_cen + nw + j * 16) = widen_pair(pc[j], pc[j + 1]);
             }
 #endif
             row_end(m, true, wm * (BM / WM) + i * 16 + fr, wn);   // main rows: wave (wm, wn) fills slot wn of its rows
@@ -1037,10 +943,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
             po[1] = bq;
         }
     }
-#if USPACE_KTRACE
-    K_STAMP(63)
-    if (ktr_on && wave < 8) g_gemm_trace[(ktr_blk * 8 + wave) * 64 + lane] = ktr;
-#endif
 }
 
 template <int BM, int BN, int WM, int WN, int FLAGS, int NST = 2>
@@ -1276,6 +1178,10 @@ inline TileChoice producer_tile(TileChoice tc, int N) {
     return tc;
 }
 
+#if USPACE_LAB
+std::atomic<int> g_force_tile{-1};        // lab builds: >= 0 overrides the planner's tile form (tools/lab/gemm_ab ... force)
+#endif
+
 template <int FLAGS>
 int dispatch_tile(const GemmArgs& a, hipStream_t s) {
 #if USPACE_FORM4
@@ -1285,6 +1191,9 @@ int dispatch_tile(const GemmArgs& a, hipStream_t s) {
     TileChoice tc = choose_tile(a.M, a.N, &m1);
     if constexpr ((FLAGS & USPACE_EPI_CEN_OUT) != 0) tc = producer_tile(tc, a.N);
     tc = refine_small(tc, a.M, a.N, a.K, (FLAGS & USPACE_EPI_CEN_OUT) != 0);
+#if USPACE_LAB
+    if (const int f = g_force_tile.load(std::memory_order_relaxed); f >= 0 && f != (int)TILE_SPLIT) tc = (TileChoice)f;
+#endif
     if constexpr ((FLAGS & (USPACE_EPI_LN_IN | USPACE_EPI_GELU)) == 0) {
         if (tc == TILE_SMALL && a.split_ws) {
             const int S = split_factor(us_cdiv(a.M, 128) * us_cdiv(a.N, 128), a.K);
@@ -1384,8 +1293,16 @@ extern "C" __attribute__((visibility("default"))) int uspace_lab_gemm_takes_form
 }
 #endif
 
+#if USPACE_LAB
+extern "C" __attribute__((visibility("default"))) void uspace_lab_gemm_force_tile(int tc) { g_force_tile.store(tc, std::memory_order_relaxed); }
+#endif
+
 extern "C" int uspace_gemm_part_slots_k(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return USPACE_ERR_ARG;
+#if USPACE_LAB
+    if (const int f = g_force_tile.load(std::memory_order_relaxed); f >= 0)
+        return us_cdiv(N, f == (int)TILE_TINY ? 64 : (f == (int)TILE_SMALL || f == (int)TILE_TALL) ? 128 : 256);
+#endif
 #if USPACE_FORM4
     // (forced four-wave form: 256-wide tiles wherever a producer launch of these sizes can take it)
     if (g_big_form.load(std::memory_order_relaxed) == 2 && uspace_lab_gemm_takes_form4(M, N, K, K, USPACE_EPI_CEN_OUT | USPACE_EPI_BIAS | USPACE_EPI_OUT_F32)) return N / 256;
@@ -1506,12 +1423,6 @@ extern "C" int uspace_gemm_bf16_ext(const uint16_t* A, int lda, const uint16_t* 
     g.wide = wide_ok(g, epi_flags);
     return dispatch_flags(g, epi_flags, (hipStream_t)stream);
 }
-
-#if USPACE_KTRACE
-extern "C" __attribute__((visibility("default"))) int uspace_lab_gemm_trace(uint32_t* dst) {
-    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gemm_trace), sizeof(g_gemm_trace)) == hipSuccess ? 0 : -1;
-}
-#endif
 
 extern "C" int uspace_gemm_bf16(const uint16_t* A, int lda, const uint16_t* A2, int lda2, int K1,
                                 const uint16_t* W, int ldw, int M, int N, int K, int epi_flags,

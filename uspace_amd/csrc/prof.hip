@@ -69,6 +69,39 @@ __global__ __launch_bounds__(256) void mfma_loop_kernel(float* out, int iters, u
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// The GEMM's own instruction on operands that toggle like real data: 16 independent v_mfma_f32_16x16x32_bf16 accumulators per wave (snake
+// order is irrelevant here: both operands change every 4 MFMAs), operand values pseudo-random in [-1, 1) with both signs, different per lane.
+// On such operands the chip is power-limited well below the 32x32x16 burst figure (profiles/r04_mfma_power_lab.txt).
+__global__ __launch_bounds__(256) void mfma16_loop_kernel(float* out, int iters, unsigned long long* cycles) {
+    const unsigned long long c0 = __builtin_readcyclecounter();
+    f32x4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 a[4], b[4];
+    uint32_t h = (threadIdx.x + 1u) * 2654435761u + blockIdx.x * 40503u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            h = h * 1664525u + 1013904223u;
+            a[q][i] = (__bf16)((float)(int)(h >> 8) * (1.0f / 8388608.0f) - 1.0f);
+            h = h * 1664525u + 1013904223u;
+            b[q][i] = (__bf16)((float)(int)(h >> 8) * (1.0f / 8388608.0f) - 1.0f);
+        }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i & 3], b[i >> 2], acc[i], 0, 0, 0);
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    if (cycles && blockIdx.x == 0 && threadIdx.x == 0) *cycles = c1 - c0;
+    f32x4 s = acc[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
 __global__ __launch_bounds__(256) void copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
@@ -153,7 +186,8 @@ extern "C" int uspace_prof_all_end(int* keys, double* total_ms, int max_records,
     return USPACE_OK;
 }
 
-extern "C" int uspace_prof_mfma_peak_clock(int iters, double* tflops, double* shader_ghz) {
+// kind 0: v_mfma_f32_32x32x16_bf16 on near-constant operands (the burst figure of the guides); 1: v_mfma_f32_16x16x32_bf16 on random operands
+static int mfma_peak(int kind, int iters, double* tflops, double* shader_ghz) {
     if (iters <= 0 || !tflops) return USPACE_ERR_ARG;
     int dev = 0;
     hipDeviceProp_t prop;
@@ -167,9 +201,10 @@ extern "C" int uspace_prof_mfma_peak_clock(int iters, double* tflops, double* sh
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL(mfma_loop_kernel, dim3(blocks), dim3(256), 0, 0, out, iters / 8 + 1, (unsigned long long*)nullptr);   // warm-up
+    auto kern = kind == 0 ? mfma_loop_kernel : mfma16_loop_kernel;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, iters / 8 + 1, (unsigned long long*)nullptr);   // warm-up
     (void)hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(mfma_loop_kernel, dim3(blocks), dim3(256), 0, 0, out, iters, cyc);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, iters, cyc);
     (void)hipEventRecord(e1, 0);
     int rc = USPACE_OK;
     float ms = 0.f;
@@ -177,7 +212,8 @@ extern "C" int uspace_prof_mfma_peak_clock(int iters, double* tflops, double* sh
     if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || hipGetLastError() != hipSuccess ||
         hipMemcpy(&hc, cyc, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = USPACE_ERR_LAUNCH;
     else {
-        *tflops = 2.0 * 32 * 32 * 16 * 32.0 * iters * 4.0 * blocks / (ms * 1e-3) / 1e12;   // 32 MFMAs per iteration per wave, 4 waves per block
+        // 32 MFMAs per iteration per wave, 4 waves per block; both instructions are 16 384 multiply-adds
+        *tflops = 2.0 * 32 * 32 * 16 * 32.0 * iters * 4.0 * blocks / (ms * 1e-3) / 1e12;
         // every workgroup runs the same loop at the same time: one workgroup's tick count over the launch's wall time is the
         // sustained shader clock under this (matrix-pipe-only) load
         if (shader_ghz) *shader_ghz = (double)hc / (ms * 1e-3) / 1e9;
@@ -188,7 +224,9 @@ extern "C" int uspace_prof_mfma_peak_clock(int iters, double* tflops, double* sh
     return rc;
 }
 
-extern "C" int uspace_prof_mfma_peak(int iters, double* tflops) { return uspace_prof_mfma_peak_clock(iters, tflops, nullptr); }
+extern "C" int uspace_prof_mfma_peak_clock(int iters, double* tflops, double* shader_ghz) { return mfma_peak(0, iters, tflops, shader_ghz); }
+extern "C" int uspace_prof_mfma_peak(int iters, double* tflops) { return mfma_peak(0, iters, tflops, nullptr); }
+extern "C" int uspace_prof_mfma_peak_gemm_op(int iters, double* tflops, double* shader_ghz) { return mfma_peak(1, iters, tflops, shader_ghz); }
 
 extern "C" int uspace_prof_hbm_copy(size_t bytes, int reps, double* gb_per_s) {
     if (bytes < (1u << 20) || reps <= 0 || !gb_per_s) return USPACE_ERR_ARG;
