@@ -762,11 +762,16 @@ def test_cnf_reuses_the_device_scalars_of_its_time_grid():
     cnf2 = CNF(Net())
     cnf2.state_ops_factory = TorchCpuOps
     cnf2.decode(x, None, dissect_name="w", edit_loc=None, solver_kwargs=sk)
-    assert cnf2._grid_is_fixed and sorted(k[1] for k in cnf2._t_scalars) == [0.0, 0.5]
+    assert sorted(k[1] for k in cnf2._t_scalars) == [0.0, 0.5]
+    # the flag lives for the duration of a solve only: a call outside one gets a fresh scalar and leaves the cache alone
+    assert not cnf2._grid_is_fixed
+    o1, _ = cnf2._timesteps(0.5, x)
+    o2, _ = cnf2._timesteps(0.5, x)
+    assert o1.data_ptr() != o2.data_ptr() and len(cnf2._t_scalars) == 2
     cnf2.decode(x, None, dissect_name="w", edit_loc=None, solver_kwargs=dict(sk, solver="adaptive"))
     assert not cnf2._grid_is_fixed and len(cnf2._t_scalars) == 2                                        # untouched by the adaptive solve
     cnf2.decode(x, None, dissect_name="w", edit_loc=None, solver_kwargs=dict(sk, solver="adaptive", n_steps=4))
-    assert cnf2._grid_is_fixed and len(cnf2._t_scalars) > 2                                             # dopri5 on 4 equal steps
+    assert not cnf2._grid_is_fixed and len(cnf2._t_scalars) > 2                                         # dopri5 on 4 equal steps cached its times
 
 
 def test_graph_replay_is_opt_in(monkeypatch):

@@ -218,6 +218,10 @@ class _FakeKernels:
         tf._obj.value, ghz._obj.value = 1.0, 1.0
         return 0
 
+    def uspace_prof_mfma_peak_gemm_op(self, iters, tf, ghz):
+        tf._obj.value, ghz._obj.value = 1.0, 1.0
+        return 0
+
     def uspace_prof_hbm_copy(self, nbytes, reps, gb):
         gb._obj.value = 1.0
         return 0

@@ -9,8 +9,10 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# (USPACE_HIP_LIB: another build of the same ABI, for A/B measurements of whole solves on one box -- tools/lab/)
-LIB_PATH = os.environ.get("USPACE_HIP_LIB") or os.path.join(_HERE, "libuspace_hip.so")
+# (USPACE_HIP_LIB: another build of the same ABI, for A/B measurements of whole solves on one box -- tools/lab/.  Lab builds can be WRONG on
+# purpose (ablations that skip stores, forms that were not landed): lib() says so on stderr and library_info() carries it into bench.py's line.)
+_DEFAULT_LIB = os.path.join(_HERE, "libuspace_hip.so")
+LIB_PATH = os.environ.get("USPACE_HIP_LIB") or _DEFAULT_LIB
 
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_OUT_BF16 = 1, 2, 4, 8, 16
 EPI_CEN_OUT, EPI_LN_IN, EPI_RANK1 = 32, 64, 128          # uspace_gemm_bf16_ext only (LayerNorm folded through the GEMMs)
@@ -140,6 +142,10 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). uspace_amd has no fallback path.")
         L = ctypes.CDLL(LIB_PATH)
+        if os.path.realpath(LIB_PATH) != os.path.realpath(_DEFAULT_LIB):
+            import sys
+            print(f"uspace_amd: USPACE_HIP_LIB overrides the product library: loading {LIB_PATH} -- a lab build, results and timings are not the "
+                  "product's", file=sys.stderr)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here = header/library mismatch
             fn.restype = res
@@ -152,6 +158,14 @@ def lib():
             L.uspace_uvit_set_ln_fold(0 if env[0] == "0" else 1)
         _lib = L
     return _lib
+
+
+def library_info():
+    """Which library is loaded: path, whether it is the in-tree product build, lab symbols it exports."""
+    L = lib()
+    lab = [s for s in ("uspace_lab_gemm_force_tile", "uspace_lab_gemm_set_big_form", "uspace_lab_gemm_trace") if hasattr(L, s)]
+    return {"path": os.path.relpath(LIB_PATH, os.path.dirname(_HERE)), "product_build": os.path.realpath(LIB_PATH) == os.path.realpath(_DEFAULT_LIB),
+            "lab_symbols": lab}
 
 
 def check(rc, what):

@@ -60,7 +60,7 @@ class CNFBase(nn.Module):
     def _timesteps(self, t, x):
         """(B,) stride-0 fp32 view of the scalar time, like ``t.expand(B)`` (flow_matching.py:33).
 
-        READ-ONLY: on a fixed time grid (``_grid_is_fixed``, set by ``_integrate`` from the solver method / ``n_steps``) the
+        READ-ONLY: on a fixed time grid (``_grid_is_fixed``, set by ``_integrate`` for the duration of its solve from the solver method / ``n_steps``) the
         device scalar behind the view is cached per (device, t) and handed out again in every later evaluation and solve -- a
         fixed-step solve visits the same times every time, and the cache saves one fill launch per evaluation.  A consumer
         that wrote into it (``t *= 1000`` in a ``_velocity`` override or a hook) would change that time for every later use;
@@ -95,10 +95,15 @@ class CNFBase(nn.Module):
             ops = HipStateOps(y0, group=self.norm_group)
         else:
             ops = None
-        # fixed grid (euler / midpoint / rk4, or an error-controlled method run on n_steps equal steps): the times repeat
+        # fixed grid (euler / midpoint / rk4, or an error-controlled method run on n_steps equal steps): the times repeat.  The flag
+        # holds for THIS solve only: a forward() / _velocity() call outside a solve (or a solve nested in a hook) gets fresh scalars
+        prev = getattr(self, "_grid_is_fixed", False)
         self._grid_is_fixed = ode_kwargs["method"] in FIXED or n_steps is not None
-        out = odeint(func, y0, float(t0), float(t1), method=ode_kwargs["method"], rtol=ode_kwargs["rtol"],
-                     atol=ode_kwargs["atol"], step_size=opts.get("step_size"), n_steps=n_steps, stats=stats, ops=ops)
+        try:
+            out = odeint(func, y0, float(t0), float(t1), method=ode_kwargs["method"], rtol=ode_kwargs["rtol"],
+                         atol=ode_kwargs["atol"], step_size=opts.get("step_size"), n_steps=n_steps, stats=stats, ops=ops)
+        finally:
+            self._grid_is_fixed = prev
         self.last_stats = stats
         return out
 
