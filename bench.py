@@ -157,12 +157,12 @@ def roofline_rows(recs, D):
     return rows
 
 
-GEMM_SOURCES = ("gemm.hip", "common.h")      # (tools/lab/gemm_chain.h is compiled only into lab variants)
+GEMM_SOURCES = ("gemm.hip", "gemm_args.h", "common.h")      # (tools/lab/gemm_chain.h is compiled only into lab variants)
 
 
 def fc1_traffic(model, B, tile):
     """HBM bytes per fc1 launch from the committed PMC pass (profiles/fc1_traffic.json) -- only when that pass was taken on the
-    GEMM sources that are being benchmarked (sha256 over gemm.hip + common.h) and on the same workload and tile form; otherwise null."""
+    GEMM sources that are being benchmarked (sha256 over gemm.hip + gemm_args.h + common.h) and on the same workload and tile form; otherwise null."""
     import hashlib
     tp = os.path.join(ROOT, "profiles", "fc1_traffic.json")
     if not os.path.exists(tp):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/fc1_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh, stamped with the sha256 of
-the GEMM sources (gemm.hip + common.h) they were measured on, the workload and the tile form (bench.py drops the figure when any of them differs).
-    python tools/make_fc1_traffic.py gpurun_out/r03_pmc_fetch.txt gpurun_out/r03_pmc_write.txt [tag]"""
+the GEMM sources (gemm.hip + gemm_args.h + common.h) they were measured on, the workload and the tile form (bench.py drops the figure when any of them differs).
+    python tools/make_fc1_traffic.py gpurun_out/<tag>_pmc_fetch.txt gpurun_out/<tag>_pmc_write.txt <tag>"""
 import hashlib
 import json
 import os
@@ -9,7 +9,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GEMM_SOURCES = ("gemm.hip", "common.h")       # as bench.py: everything the GEMM kernels are compiled from
+GEMM_SOURCES = ("gemm.hip", "gemm_args.h", "common.h")       # as bench.py: everything the GEMM kernels are compiled from
 FC1 = re.compile(r"gemm_kernel<(\d+), (\d+), \d, \d, 83, (true|false)")      # LN_IN|BIAS|GELU|OUT_BF16 = 64+1+2+16
 
 
@@ -31,7 +31,9 @@ def per_launch(path, counter):
 
 def main():
     fetch, write = sys.argv[1], sys.argv[2]
-    tag = sys.argv[3] if len(sys.argv) > 3 else "r03"
+    if len(sys.argv) <= 3:
+        raise SystemExit("make_fc1_traffic.py: name the round (third argument, e.g. r05)")
+    tag = sys.argv[3]
     f_kb, n, m = per_launch(fetch, "FETCH_SIZE")
     w_kb, _, _ = per_launch(write, "WRITE_SIZE")
     M, N, K = 64 * 257, 4096, 1024
