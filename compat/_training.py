@@ -53,15 +53,19 @@ def reference_twin(net, overlay):
     return twin
 
 
-def flow_matching_loss(velocity, x, sigma_min):
-    """flow_matching.py:88-100: x_t = t x + (1 - (1 - sigma) t) eps, target u = x - (1 - sigma) eps, mean squared error per sample.
-    Random draws in the reference's order (noise, then t)."""
-    noise = torch.randn_like(x)
-    t = torch.rand(len(x), device=x.device, dtype=x.dtype)
-    t_ = t[:, None, None, None]
-    x_new = t_ * x + (1 - (1 - sigma_min) * t_) * noise
-    u = x - (1 - sigma_min) * noise
-    return (velocity(t, x_new) - u).square().mean(dim=(1, 2, 3))
+def flow_matching_loss(velocity, x1, sigma_min):
+    """The conditional flow-matching objective of flow_matching.py:88-100 for one batch of data latents x1: a point on the straight path
+    from noise to data, x_t = t x1 + (1 - (1 - sigma) t) eps, whose target velocity is d x_t / dt = x1 - (1 - sigma) eps; squared error of
+    `velocity(t, x_t)` against it, averaged per sample.  The two random draws come in the reference's order (eps first, then t), so a
+    seeded script sees the same numbers."""
+    eps = torch.randn_like(x1)
+    t = torch.rand(x1.shape[0], device=x1.device, dtype=x1.dtype)
+    tb = t.view(-1, 1, 1, 1)
+    keep = 1.0 - sigma_min
+    x_t = tb * x1 + (1.0 - keep * tb) * eps
+    target = x1 - keep * eps
+    err = velocity(t, x_t) - target
+    return (err * err).mean(dim=(1, 2, 3))
 
 
 def unwrap(net):
