@@ -785,27 +785,32 @@ def test_graph_replay_is_opt_in(monkeypatch):
 
 
 def test_measurement_switches_cannot_reach_a_product_build():
-    """gemm.hip's ablation / A-B switches (two of them produce wrong results on purpose) exist only under -DUSPACE_LAB=1, which
-    only tools/lab/build_variant.sh defines: csrc/Makefile builds with -DUSPACE_LAB=0 -Werror=undef, naming a switch without the
-    lab flag is a preprocessor error, and no build debris (-save-temps output) is tracked next to the sources."""
+    """gemm.hip's lab hooks (tile-form override, the four-wave form of tools/lab/gemm4, the chain form) exist only under -DUSPACE_LAB=1,
+    which only the lab build scripts define: csrc/Makefile builds with -DUSPACE_LAB=0 -Werror=undef, naming a hook without the lab flag is a
+    preprocessor error, the switches that produced wrong results on purpose (ablations, same-panel staging) are gone from the source
+    (patches under tools/lab/dropped/), and no build debris (-save-temps output) is tracked next to the sources."""
     import shutil
     import subprocess
     csrc = os.path.join(ROOT, "uspace_amd", "csrc")
     mk = open(os.path.join(csrc, "Makefile")).read()
-    assert "-DUSPACE_LAB=0" in mk and "-Werror=undef" in mk and "USPACE_LAB=1" not in mk
-    assert "USPACE_ABLATE" not in mk and "-DUSPACE_LAB=1" in open(os.path.join(ROOT, "tools", "lab", "build_variant.sh")).read()
+    assert "-DUSPACE_LAB=0" in mk and "-Werror=undef" in mk and "USPACE_LAB=1" not in mk and "gemm4" not in mk
+    assert "-DUSPACE_LAB=1" in open(os.path.join(ROOT, "tools", "lab", "build_variant.sh")).read()
+    assert "-DUSPACE_LAB=1" in open(os.path.join(ROOT, "tools", "lab", "gemm4", "build.sh")).read()
     src = open(os.path.join(csrc, "gemm.hip")).read()
-    for m in re.finditer(r"^#\s*if(?:n?def)?\s+.*USPACE_ABLATE_\w+.*$", src, re.M):
-        line = m.group(0)
-        # every site tests the VALUE (0 in a product build), or sits in the guarded definition block at the top
-        assert line.startswith(("#if USPACE_ABLATE_", "#if !USPACE_ABLATE_", "#ifndef USPACE_ABLATE_", "#if defined(USPACE_ABLATE_")), line
+    for gone in ("USPACE_ABLATE", "USPACE_SAME_PANELS", "USPACE_DMA_FLAT", "USPACE_KTRACE", "USPACE_FULL_LINES", "K_STAMP"):
+        assert gone not in src, gone
+    # every lab-only region is fenced by the VALUE of a hook that is 0 in a product build
+    for m in re.finditer(r"^#\s*if\s+(.*)$", src, re.M):
+        cond = m.group(1)
+        if "USPACE_" in cond and "defined" not in cond:
+            assert re.fullmatch(r"!?USPACE_(LAB|FORM4|CHAIN)\s*", cond), cond
     hipcc = "/opt/rocm/bin/hipcc"
     if os.path.exists(hipcc):
         base = [hipcc, "-std=c++17", "--offload-arch=gfx950", "--cuda-host-only", "-E", "-o", os.devnull, os.path.join(csrc, "gemm.hip")]
-        for sw in ("USPACE_ABLATE_NOSTORE", "USPACE_ABLATE_NOEPI", "USPACE_DMA_FLAT=1"):
+        for sw in ("USPACE_FORM4=1", "USPACE_CHAIN=1", "USPACE_CHAIN_BODY=8"):
             r = subprocess.run(base + ["-DUSPACE_LAB=0", "-D" + sw], capture_output=True, text=True)
-            assert r.returncode != 0 and "measurement switches need -DUSPACE_LAB=1" in r.stderr, (sw, r.stderr[-300:])
-        assert subprocess.run(base + ["-DUSPACE_LAB=1", "-DUSPACE_ABLATE_NOSTORE=1"], capture_output=True).returncode == 0
+            assert r.returncode != 0 and "lab hooks need -DUSPACE_LAB=1" in r.stderr, (sw, r.stderr[-300:])
+        assert subprocess.run(base + ["-DUSPACE_LAB=1", "-DUSPACE_FORM4=1"], capture_output=True).returncode == 0
     if shutil.which("git") and os.path.isdir(os.path.join(ROOT, ".git")):
         tracked = subprocess.run(["git", "-C", ROOT, "ls-files", "uspace_amd"], capture_output=True, text=True).stdout.split()
         junk = [f for f in tracked if f.endswith((".s", ".bc", ".hipi", ".o", ".so")) or "/lib.so." in f or "hipv4-amdgcn" in f]

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/lab/build_variant.sh <name> <source.hip of uspace_amd/csrc> "<extra hipcc flags>"  ->  tools/lab/_build/lib_<name>.so
-# The only place that defines USPACE_LAB=1 (the measurement switches of gemm.hip: USPACE_ABLATE_*, USPACE_DMA_FLAT, ...).
+# Defines USPACE_LAB=1 (the lab hooks of gemm.hip: tile-form override, USPACE_CHAIN; older switches are patches under tools/lab/dropped/).
 # (the other objects come from the product build: run `make -C uspace_amd/csrc` first)
 set -e
 NAME=$1; SRC=$2; EXTRA=$3

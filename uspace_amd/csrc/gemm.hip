@@ -27,61 +27,28 @@ namespace {
 using namespace usgemm;
 
 
-// Measurement switches.  The A/B and ablation builds behind `profiles/r0*_gemm_ablation.md` exist only under -DUSPACE_LAB=1, which
-// `tools/lab/build_variant.sh` passes and `csrc/Makefile` never does (it builds with -DUSPACE_LAB=0 -Werror=undef): a product build
-// that names one of them stops here, and the two switches that produce wrong results on purpose (NOSTORE, NOEPI) cannot reach it.
+// Lab hooks.  What is left of the measurement switches of rounds 1-5 (the ablations, the flat LDS-DMA form, MFMA orders, K-loop stamps, full-line
+// stores, same-panel staging ... are patches under tools/lab/dropped/ now: `gemm_lab_switches_r05.patch`, `gemm_ktrace_fulllines_r04.patch`) exists
+// only under -DUSPACE_LAB=1, which `tools/lab/build_variant.sh` / `tools/lab/gemm4/build.sh` pass and `csrc/Makefile` never does (it builds with
+// -DUSPACE_LAB=0 -Werror=undef): a product build that names one of them stops here.
+//   USPACE_LAB    1: `uspace_lab_gemm_force_tile` overrides the planner's tile form (tools/lab/gemm_ab ... tileA tileB)
+//   USPACE_FORM4  1: 256x256 launches may take the four-wave form of tools/lab/gemm4/ (round 5; lab builds link gemm4.o)
+//   USPACE_CHAIN  1: multi-round store-only launches of 256x256 tiles take the chain form (tools/lab/gemm_chain.h, round 4)
 #ifndef USPACE_LAB
 #define USPACE_LAB 0
 #endif
 #if !USPACE_LAB
-#if defined(USPACE_ABLATE_NOSTORE) || defined(USPACE_ABLATE_NOEPI) || defined(USPACE_ABLATE_NOGELU) || defined(USPACE_DMA_FLAT) || \
-    defined(USPACE_RING_PREFETCH_ALL) || defined(USPACE_TINY_UNROLL) || defined(USPACE_EARLY_BARRIER) || defined(USPACE_TALL_COST) || defined(USPACE_CHAIN) || \
-    defined(USPACE_CHAIN_ABL) || defined(USPACE_CHAIN_DMA8) || defined(USPACE_CHAIN_SPLIT) || defined(USPACE_CHAIN_BODY) || defined(USPACE_MMA_ORDER) || defined(USPACE_FORM4) || defined(USPACE_SAME_PANELS)
-#error "measurement switches need -DUSPACE_LAB=1 (tools/lab/build_variant.sh); the product build takes none"
+#if defined(USPACE_CHAIN) || defined(USPACE_CHAIN_ABL) || defined(USPACE_CHAIN_DMA8) || defined(USPACE_CHAIN_SPLIT) || defined(USPACE_CHAIN_BODY) || defined(USPACE_FORM4)
+#error "lab hooks need -DUSPACE_LAB=1 (tools/lab/build_variant.sh); the product build takes none"
 #endif
-#define USPACE_ABLATE_NOSTORE 0
-#define USPACE_ABLATE_NOEPI 0
-#define USPACE_ABLATE_NOGELU 0
-#else
-#ifndef USPACE_ABLATE_NOSTORE
-#define USPACE_ABLATE_NOSTORE 0  /* 1: the epilogue computes and stores nothing (wrong results; timing only) */
-#endif
-#ifndef USPACE_ABLATE_NOEPI
-#define USPACE_ABLATE_NOEPI 0    /* 1: the kernel ends behind its K loop (wrong results; timing only) */
-#endif
-#ifndef USPACE_ABLATE_NOGELU
-#define USPACE_ABLATE_NOGELU 0   /* 1: fc1 without its activation (wrong results; timing only) */
-#endif
-#endif
-#ifndef USPACE_TALL_COST
-#define USPACE_TALL_COST 0.60    // one round of 256x128 tiles in units of a round of 256x256 tiles (measured, r02_gemm_ablation.md)
-#endif
-#ifndef USPACE_DMA_FLAT
-#define USPACE_DMA_FLAT 0        // 1: the round-2 flat global_load_lds form (A/B measurements)
-#endif
-#ifndef USPACE_RING_PREFETCH_ALL
-#define USPACE_RING_PREFETCH_ALL 0
-#endif
-#ifndef USPACE_TINY_UNROLL
-#define USPACE_TINY_UNROLL 1
-#endif
-#ifndef USPACE_MMA_ORDER
-// order of a phase's independent MFMAs: 1 = snake over the wave's sub-tiles (exactly one operand register changes between consecutive MFMAs: the pure
-// MFMA stream sustains 2.07 instead of 2.03 PFLOP/s on random operands, `profiles/r04_mfma_power_lab.txt`; fc1 -1 % in the A/B, bit-equal), 0 = rows outer /
-// columns inner (rounds 1-4), 2 = columns outer.  0 and 2 are lab settings.
-#define USPACE_MMA_ORDER 1
-#endif
-#ifndef USPACE_SAME_PANELS
-// (lab, wrong results, timing only -- VERDICT r4 task 3: what is the fabric traffic of the operand panels worth?) bit 0: every workgroup of an XCD
-// stages the SAME 256 activation rows, bit 1: the same 256 weight rows: after first touch its operands come from its L2, nothing through the fabric
-#define USPACE_SAME_PANELS 0
 #endif
 #ifndef USPACE_FORM4
-#define USPACE_FORM4 0           // 1: 256x256 launches may take the four-wave form of tools/lab/gemm4/ (round 5; lab builds link gemm4.o)
+#define USPACE_FORM4 0
 #endif
 #ifndef USPACE_CHAIN
-#define USPACE_CHAIN 0           // 1: multi-round store-only launches of 256x256 tiles take the chain form (gemm_chain.h)
+#define USPACE_CHAIN 0
 #endif
+constexpr double TALL_COST = 0.60;   // one round of 256x128 tiles in units of a round of 256x256 tiles (measured, profiles/r02_gemm_ablation.md)
 constexpr int ROW_BYTES = 128;
 
 // wave row `wm` owns extra-strip sub-tiles [wm*XN, wm*XN+XN) of its TN weight fragments (select chain:
@@ -231,7 +198,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
     for (int i = 0; i < ISSUES_A; ++i) {
         const int r = i * ROWS_PER_ISSUE + srow;
         const int c = schunk ^ ((r >> 1) & 7);
-        int m = ((USPACE_SAME_PANELS & 1) ? (int)(blockIdx.x & 7) * BM : m0) + r;
+        int m = m0 + r;
         m = m < m_lim ? m : m_lim - 1;
         a_off[i] = (uint32_t)(m * g.lda + c * 8) * 2u;
     }
@@ -239,7 +206,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
     for (int i = 0; i < ISSUES_W; ++i) {
         const int r = i * ROWS_PER_ISSUE + srow;
         const int c = schunk ^ ((r >> 1) & 7);
-        int n = ((USPACE_SAME_PANELS & 2) ? (int)(blockIdx.x & 7) * BN : n0) + r;
+        int n = n0 + r;
         n = n < g.N ? n : g.N - 1;
         w_off[i] = (uint32_t)(n * g.ldw + c * 8) * 2u;
     }
@@ -272,11 +239,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
     // form global_load_lds needed a 64-bit VALU add into the same address register pair before every instruction -- the zero
     // extension of the offsets was hoisted out of the loop, so the scalar-base addressing mode never matched -- and each add had to
     // wait for the previous instruction to have read that pair: 80-130 cycles per DMA instruction, `profiles/r03_gemm_ablation.md`.)
-    auto dma16 = [&](const char* ubase, const __amdgpu_buffer_rsrc_t& rs, uint32_t voff, char* lds) {
-        if constexpr (USPACE_DMA_FLAT != 0)
-            __builtin_amdgcn_global_load_lds((const US_GLB void*)(ubase + voff), (US_LDS void*)lds, 16, 0, 0);
-        else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (US_LDS void*)lds, 16, voff, 0, 0, 0);
+    auto dma16 = [&](const __amdgpu_buffer_rsrc_t& rs, uint32_t voff, char* lds) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (US_LDS void*)lds, 16, voff, 0, 0, 0);
     };
     // (do_x: stage the strip's rows as well -- has_x by default; the strip-free copy of the K loop passes a constant false)
     auto stage_a = [&](int kt, int buf, bool do_x) {
@@ -285,9 +249,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         const char* abase = a_base(k0);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)abase, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < ISSUES_A; ++i) dma16(abase, rs, a_off[i], base + i * ROWS_PER_ISSUE * ROW_BYTES + wave_lds_off);
+        for (int i = 0; i < ISSUES_A; ++i) dma16(rs, a_off[i], base + i * ROWS_PER_ISSUE * ROW_BYTES + wave_lds_off);
         if constexpr (XTRA) {
-            if (do_x && wave < 2) dma16(abase, rs, x_off, base + TILE_A_BYTES + TILE_W_BYTES + wave_lds_off);
+            if (do_x && wave < 2) dma16(rs, x_off, base + TILE_A_BYTES + TILE_W_BYTES + wave_lds_off);
         }
     };
     auto stage_w = [&](int kt, int buf) {
@@ -295,7 +259,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         char* base = smem + buf * STAGE_BYTES + TILE_A_BYTES;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < ISSUES_W; ++i) dma16(wbase, rs, w_off[i], base + i * ROWS_PER_ISSUE * ROW_BYTES + wave_lds_off);
+        for (int i = 0; i < ISSUES_W; ++i) dma16(rs, w_off[i], base + i * ROWS_PER_ISSUE * ROW_BYTES + wave_lds_off);
     };
 
     const int fr = lane & 15;   // fragment row (m for activations, n for weights)
@@ -383,21 +347,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
     _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_)                                               \
         dst[j_] = *(const bf16x8*)((base) + w_lds + j_ * 16 * ROW_BYTES + (ck));
 #define LOAD_X(dst, base, ck) if (X_ON) dst = *(const bf16x8*)((base) + x_lds + (ck));
-#if USPACE_MMA_ORDER == 2
-#define MMA(af, wf, mh, ilo, ihi)                                                                   \
-    _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_)                                               \
-        _Pragma("unroll") for (int i_ = (ilo); i_ < (ihi); ++i_)                                    \
-            acc[(mh) * HM + i_][j_] =                                                               \
-                __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j_], af[i_], acc[(mh) * HM + i_][j_], 0, 0, 0);
-#else
+// a phase's independent MFMAs in snake order over the wave's sub-tiles: exactly one operand register changes between consecutive MFMAs (the pure MFMA
+// stream sustains 2.07 instead of 2.03 PFLOP/s on random operands, `profiles/r04_mfma_power_lab.txt`; fc1 -1 % in the A/B, bit-equal)
 #define MMA(af, wf, mh, ilo, ihi)                                                                   \
     _Pragma("unroll") for (int i_ = (ilo); i_ < (ihi); ++i_)                                        \
         _Pragma("unroll") for (int jj_ = 0; jj_ < TN; ++jj_) {                                      \
-            const int j_ = (USPACE_MMA_ORDER == 1 && (i_ & 1)) ? TN - 1 - jj_ : jj_;                \
+            const int j_ = (i_ & 1) ? TN - 1 - jj_ : jj_;                                           \
             acc[(mh) * HM + i_][j_] =                                                               \
                 __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j_], af[i_], acc[(mh) * HM + i_][j_], 0, 0, 0); \
         }
-#endif
 #define MMA_X(xf, wf)                                                                               \
     if (XTRA && X_ON) {                                                                             \
         _Pragma("unroll") for (int j_ = 0; j_ < XN; ++j_)                                           \
@@ -485,7 +443,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         }
     }
     // 64 x 64 tiles in the ring form keep the fragments of a whole K tile in registers, fetched one tile ahead (see KTILE_T below)
-    constexpr bool TINYK = NST > 2 && ((BM == 64 && BN == 64) || USPACE_RING_PREFETCH_ALL);
+    constexpr bool TINYK = NST > 2 && BM == 64 && BN == 64;
     if constexpr (!TINYK) {
         LOAD_A(af0, smem, 0, c_k0)
         LOAD_W(wf0, smem, c_k0)
@@ -495,10 +453,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
     // Where the per-K-tile barrier sits: behind all but the last HM/2 row blocks' MFMAs of the tile (the 8 MFMAs left cover the next tile's first
     // fragment reads), or one step earlier (16 left) for the 256x128 form, whose MFMA phases are half as long (`profiles/r03_gemm_ablation.md` section 24;
     // for the 256x256 form the earlier barrier is neutral and costs registers)
-#ifndef USPACE_EARLY_BARRIER
-#define USPACE_EARLY_BARRIER (BM == 256 && BN == 128)
-#endif
-    constexpr bool EARLYB = USPACE_EARLY_BARRIER;
+    constexpr bool EARLYB = BM == 256 && BN == 128;
 #define KTILE(kt, MORE, MORE2)                                                                     \
     {                                                                                              \
         const char* cur = smem + (kt & 1) * STAGE_BYTES;                                           \
@@ -650,7 +605,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
             __builtin_amdgcn_sched_barrier(0);                                                     \
             ++kt;                                                                                  \
         }
-        if constexpr (NST == 4 && USPACE_TINY_UNROLL) {
+        if constexpr (NST == 4) {
             while (kt + 2 * NST - 1 < nk) {       // all four tiles of the turn refill (tile kt+7 exists); buf is 0 before and after
                 KTILE_TC(0, 1, 0)
                 KTILE_TC(1, 0, 1)
@@ -756,10 +711,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         return v;
     };
     auto emit_post = [&](const f32x4& v, int m, int n) {
-#if USPACE_ABLATE_NOSTORE
-        asm volatile("" ::"v"(v));
-        return;
-#endif
         if constexpr (FLAGS & USPACE_EPI_OUT_F32) {
             *(f32x4*)(out_f32 + (size_t)m * g.ld_f32 + n) = v;
         }
@@ -833,17 +784,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         }
     };
     const bool interior = (m0 + BM <= m_lim) && (n0 + BN <= g.N);   // workgroup-uniform
-#if USPACE_ABLATE_NOEPI
-    {
-        float sacc = 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-        if (sacc == 1.2345e30f) g.out_bf16[tid] = 1;
-        return;
-    }
-#endif
     if (interior && g.wide) {
         const int nw = n0 + wn * (BN / WN) + (fq & 1) * 16 + (fq >> 1) * 8;   // this lane's column in a widened pair (+ 32 per pair)
 #pragma unroll
@@ -854,9 +794,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
             f32x4 v[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j) v[j] = emit_pre(acc[i][j], bias4[j], cs4[CSV ? j : 0]);
-#if !USPACE_ABLATE_NOGELU
             if constexpr (FLAGS & USPACE_EPI_GELU) gelu_erf_batch<TN>(v);
-#endif
             uint2 pk[TN], pc[TN];
             f32x4 s1v = {0.f, 0.f, 0.f, 0.f}, s2v = {0.f, 0.f, 0.f, 0.f};   // CEN: the row's sums as packed vector accumulators
 #pragma unroll
@@ -878,13 +816,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
                 ps1 = (s1v[0] + s1v[1]) + (s1v[2] + s1v[3]);
                 ps2 = (s2v[0] + s2v[1]) + (s2v[2] + s2v[3]);
             }
-#if !USPACE_ABLATE_NOSTORE
 #pragma unroll
             for (int j = 0; j < TN; j += 2) {
                 if constexpr (FLAGS & USPACE_EPI_OUT_BF16) *(uint4*)(g.out_bf16 + (size_t)m * g.ld_bf16 + nw + j * 16) = widen_pair(pk[j], pk[j + 1]);
                 if constexpr (CEN) *(uint4*)(g.out_cen + (size_t)m * g.ld_cen + nw + j * 16) = widen_pair(pc[j], pc[j + 1]);
             }
-#endif
             row_end(m, true, wm * (BM / WM) + i * 16 + fr, wn);   // main rows: wave (wm, wn) fills slot wn of its rows
         }
     } else {
@@ -1102,7 +1038,7 @@ enum TileChoice { TILE_BIG = 0, TILE_MID = 1, TILE_SMALL = 2, TILE_SPLIT = 3, TI
 // Four tile configurations, chosen by a round-count cost model (unit: one round of 256x256 tiles):
 //   256x256, 8 waves (2x4), ~130 KiB LDS, 1 workgroup/CU     cost 1.00 per round of 256 tiles
 //   192x256, 8 waves (2x4), ~112 KiB LDS, 1 workgroup/CU     cost 0.80 (3/4 of the work, same fixed costs)
-//   256x128, 8 waves (4x2), ~100 KiB LDS, 1 workgroup/CU     cost USPACE_TALL_COST (half the work, 3/4 of the staging)
+//   256x128, 8 waves (4x2), ~100 KiB LDS, 1 workgroup/CU     cost TALL_COST (half the work, 3/4 of the staging)
 //   128x128, 4 waves (2x2),  ~66 KiB LDS, 2 workgroups/CU    cost 0.68 per round of 512 tiles, 0.50 for <= 256 (one per CU)
 // (measured per round on the U-ViT-L shapes at 1 028 ... 16 448 rows, `profiles/r02_gemm_ablation.md` section 6)
 // plus the split form: whole rounds of 256x256 tiles and the remaining rows as one round of 128x128 tiles (rows
@@ -1126,7 +1062,7 @@ TileChoice choose_tile(int M, int N, int* split_rows) {
     const double cost_mid = us_cdiv(pm.tiles_m * tn, 256) * strip(pm, 192) * 0.80;
     const int tn_tall = us_cdiv(a.N, 128);
     const Plan pt = plan_rows(a.M, 256, tn_tall, 256);
-    const double cost_tall = a.M >= 256 ? us_cdiv(pt.tiles_m * tn_tall, 256) * strip(pt, 256) * USPACE_TALL_COST : 1e30;
+    const double cost_tall = a.M >= 256 ? us_cdiv(pt.tiles_m * tn_tall, 256) * strip(pt, 256) * TALL_COST : 1e30;
     double cost_split = 1e30;
     int m1 = 0;
     const int full_rounds = (int)(big_tiles / 256);
