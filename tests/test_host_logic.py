@@ -2,6 +2,7 @@
 import ctypes
 import json
 import os
+import sys
 import re
 
 import numpy as np
@@ -815,6 +816,20 @@ def test_measurement_switches_cannot_reach_a_product_build():
         tracked = subprocess.run(["git", "-C", ROOT, "ls-files", "uspace_amd"], capture_output=True, text=True).stdout.split()
         junk = [f for f in tracked if f.endswith((".s", ".bc", ".hipi", ".o", ".so")) or "/lib.so." in f or "hipv4-amdgcn" in f]
         assert not junk, junk
+
+
+def test_lab_k_loop_text_matches_its_generator():
+    """tools/lab/gemm4/kloop4.inc (the assembly K loop of the four-wave GEMM form, measured in round 5 and not landed) is generated text:
+    the committed file must be what the committed generator writes with its default knobs."""
+    import subprocess
+    gen = os.path.join(ROOT, "tools", "lab", "gemm4", "gen_kloop4.py")
+    r = subprocess.run([sys.executable, gen, "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    txt = open(os.path.join(ROOT, "tools", "lab", "gemm4", "kloop4.inc")).read()
+    for form in ("KLOOP4_TEXT_00", "KLOOP4_TEXT_01", "KLOOP4_TEXT_10", "KLOOP4_TEXT_11", "KLOOP4_CLOBBERS", "KLOOP4_READ_ROW_7"):
+        assert "#define " + form in txt
+    # every text: 4 tile variants x 128 MFMAs on the main accumulators (+ 4 x 2 x 8 strip MFMAs in the strip forms)
+    assert txt.count("v_mfma_f32_16x16x32_bf16 a[") == 4 * 512
 
 
 def test_two_workspaces_stay_resident_lru():
