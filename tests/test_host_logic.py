@@ -832,6 +832,21 @@ def test_lab_k_loop_text_matches_its_generator():
     assert txt.count("v_mfma_f32_16x16x32_bf16 a[") == 4 * 512
 
 
+def test_gelu_polynomial_in_the_header_keeps_its_stated_accuracy():
+    """The fused erf-GELU epilogue evaluates exp2 of a polynomial (uspace_amd/csrc/common.h, US_GELU_C*; fitted by tools/fit_gelu.py).
+    The coefficients as committed, evaluated the way the kernel does (fp32 Horner, one rounding per fma), stay within the bounds the
+    header states against the exact erfc form of nn.GELU (reference libs/timm.py:97) -- three orders of magnitude below the bf16
+    rounding of the stored activation; the GPU parity tests compare the kernel itself with libm's erf."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fit_gelu", os.path.join(ROOT, "tools", "fit_gelu.py"))
+    fg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fg)
+    c = fg.header_coefficients()
+    assert len(c) == 7                                       # degree 6: the kernel's Horner chain is written for exactly that
+    e_abs, e_rel = fg.errors(c)
+    assert e_abs <= 4.1e-7 and e_rel <= 1.0e-6, (e_abs, e_rel)
+
+
 def test_two_workspaces_stay_resident_lru():
     """The write_scales sweep (one 9 x B solve) next to plain B solves alternates two batch sizes: neither switch reallocates;
     a third size evicts the least recently used one.  (Sizes come from the library's own query; CPU memory stands in here.)"""

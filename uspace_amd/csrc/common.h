@@ -41,27 +41,26 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // erf-GELU (nn.GELU default, reference libs/timm.py:97):  gelu(v) = v Phi(v) = max(v, 0) - |v| w(|v|),  w(x) = Phi(-x) = erfc(x / sqrt 2) / 2.
-// log2 w(x) is smooth and nearly quadratic, so  w(x) = exp2(P(x))  with a degree-8 polynomial (weighted minimax fit on [0, 8] for the
-// absolute error of |v| w, evaluated in fp32 Horner form; beyond 8, |v| w < 1e-14 and x is clamped): |gelu - exact| <= 4.4e-7 |v|,
-// the fp32 rounding of v itself, far below the bf16 rounding of the stored result (the parity tests compare with libm's erf).
-// One v_exp_f32 and ten plain VALU operations per value; no reciprocal, no sign handling (the |.| and -|.| are source modifiers).
-// Round 1-2 used Abramowitz-Stegun 7.1.26 (v_rcp + v_exp + 12 operations, same accuracy): the fc1 epilogue is VALU-bound
-// (`profiles/r03_gemm_ablation.md` sections 2 and 15), libm's branchy erff cost ~16 us per 256x256 tile round before that.
+// log2 w(x) is smooth and nearly quadratic, so  w(x) = exp2(P(x))  with a degree-6 polynomial (`tools/fit_gelu.py`: reweighted minimax
+// fit on [0, 8] of the error of |v| w, weighted x / (x + 1/4) so that small |v| are held relative to |v|; evaluated in fp32 Horner
+// form; beyond 8, |v| w < 1e-14 and x is clamped): |gelu - exact| <= 4.1e-7 absolute and <= 1.0e-6 |v| over [-12, 12] in fp32 --
+// the fp32 rounding of v itself is 6e-8 |v|, the bf16 rounding of the stored result 2e-3 |result| (the parity tests compare with libm's erf).
+// One v_exp_f32 and eight plain VALU operations per value; no reciprocal, no sign handling (the |.| and -|.| are source modifiers).
+// Round 1-2 used Abramowitz-Stegun 7.1.26 (v_rcp + v_exp + 12 operations), rounds 3-4 a degree-8 fit that was no more accurate
+// (2.5e-7 absolute) because it had not been driven to the minimax: the fc1 epilogue is VALU-bound (`profiles/r03_gemm_ablation.md`
+// sections 2 and 15) and the two stages less are worth 3.6 % of fc1, 0.6 % of a forward (`profiles/r05_gelu6.md`; degree 5 -- 1e-6
+// absolute -- is not faster than 6).
 #define US_GELU_X 8.0f
-#define US_GELU_C0 (-9.999988739e-01f)
-#define US_GELU_C1 (-1.151123263e+00f)
-#define US_GELU_C2 (-4.591154377e-01f)
-#define US_GELU_C3 (-5.271419817e-02f)
-#define US_GELU_C4 7.333383560e-03f
-#define US_GELU_C5 (-3.233417964e-04f)
-#define US_GELU_C6 (-1.144627951e-04f)
-#define US_GELU_C7 2.508332872e-05f
-#define US_GELU_C8 (-1.690403274e-06f)
+#define US_GELU_C0 (-9.999973281e-01f)
+#define US_GELU_C1 (-1.151154423e+00f)
+#define US_GELU_C2 (-4.589331610e-01f)
+#define US_GELU_C3 (-5.317212217e-02f)
+#define US_GELU_C4 7.911135497e-03f
+#define US_GELU_C5 (-7.132332882e-04f)
+#define US_GELU_C6 2.619813689e-05f
 __device__ __forceinline__ float gelu_erf(float v) {
     const float x = fminf(fabsf(v), US_GELU_X);
-    float q = fmaf(US_GELU_C8, x, US_GELU_C7);
-    q = fmaf(q, x, US_GELU_C6);
-    q = fmaf(q, x, US_GELU_C5);
+    float q = fmaf(US_GELU_C6, x, US_GELU_C5);
     q = fmaf(q, x, US_GELU_C4);
     q = fmaf(q, x, US_GELU_C3);
     q = fmaf(q, x, US_GELU_C2);
@@ -87,13 +86,11 @@ __device__ __forceinline__ void gelu_erf_batch(f32x4 (&v)[NV]) {
         for (int c = 0; c < 4; ++c) asm("v_min_f32 %0, |%1|, %2" : "=v"(x[j][c]) : "v"(v[j][c]), "s"(US_GELU_X));
     US_STAGE_END(x)
 #pragma unroll
-    for (int j = 0; j < NV; ++j) q[j] = x[j] * US_GELU_C8 + US_GELU_C7;
+    for (int j = 0; j < NV; ++j) q[j] = x[j] * US_GELU_C6 + US_GELU_C5;
     US_STAGE_END(q)
 #define US_GELU_STEP(CK)                                           \
     _Pragma("unroll") for (int j = 0; j < NV; ++j) q[j] = q[j] * x[j] + (CK); \
     US_STAGE_END(q)
-    US_GELU_STEP(US_GELU_C6)
-    US_GELU_STEP(US_GELU_C5)
     US_GELU_STEP(US_GELU_C4)
     US_GELU_STEP(US_GELU_C3)
     US_GELU_STEP(US_GELU_C2)
