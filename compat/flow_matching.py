@@ -22,6 +22,7 @@ class CNF(_CNF):
         twin = _training.reference_twin(net, _overlay)
         if twin is None:
             return super().training_losses(x, y, sigma_min, **kwargs)        # raises: nothing to delegate to
+        twin.train(net.training)                 # the script's nnet.train() / .eval() reaches the twin too
         kwargs.setdefault("edit_loc", None)      # libs/uvit.py:313 reads it unconditionally
         return _training.flow_matching_loss(lambda t, xt: twin(xt, t, y, **kwargs)[0], x, sigma_min)
 

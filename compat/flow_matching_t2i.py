@@ -21,6 +21,7 @@ class CNF(_CNF):
         twin = _training.reference_twin(net, _overlay)
         if twin is None:
             return super().training_losses(x, context, sigma_min, **kwargs)
+        twin.train(net.training)                 # the script's nnet.train() / .eval() reaches the twin too
         return _training.flow_matching_loss(lambda t, xt: twin(xt, t, context=context, **kwargs)[0], x, sigma_min)
 
 
