@@ -329,7 +329,9 @@ def main():
     def solver_kwargs(kind):
         sk = dict(solver_fix="euler", solver_fix_step=1.0 / args.ode_steps, solver_adaptive="dopri5",
                   solver_adaptive_prec=0.01, n_steps=args.ode_steps)
-        sk["solver"] = "adaptive" if kind == "dopri5" else "fixed"
+        sk["solver"] = "adaptive" if kind in ("dopri5", "dopri5_adaptive") else "fixed"
+        if kind == "dopri5_adaptive":          # the reference's default sampler: error-controlled dopri5 at rtol = atol = 1e-5
+            del sk["n_steps"]                  # (flow_matching.py:78-84); the NFE is data-dependent
         return sk
 
     last_local = [None]
@@ -418,6 +420,37 @@ def main():
             if world > 1:
                 dist.all_reduce(e, op=dist.ReduceOp.MAX)
             extra = dict(euler50_images_per_sec=B * world / float(e.item()), euler50_nfe=cnf.last_stats.nfe)
+            # the reference-default sampler (adaptive dopri5, rtol = atol = 1e-5), outside the timed region.  Per-rank step
+            # control (the reference under `accelerate launch`; every rank its own NFE) and, for N > 1, the group-controlled form
+            # (CNF.norm_group: one all-reduced error norm per step attempt, the step sequence of the unsharded solve on every rank)
+            def adaptive_reading(tag, group):
+                prev = cnf.norm_group
+                cnf.norm_group = group
+                try:
+                    solve("dopri5_adaptive")
+                    fence()
+                    t3 = time.perf_counter()
+                    solve("dopri5_adaptive")
+                    fence()
+                    st = cnf.last_stats
+                    a = torch.tensor([time.perf_counter() - t3, st.nfe, st.accepted, st.rejected], dtype=torch.float64, device=dev)
+                    rows = [a]
+                    if world > 1:
+                        rows = [torch.empty_like(a) for _ in range(world)]
+                        dist.all_gather(rows, a)
+                    rows = [[float(v) for v in r.tolist()] for r in rows]
+                    wall = max(r[0] for r in rows)
+                    extra[f"{tag}_images_per_sec"] = B * world / wall
+                    extra[f"{tag}_nfe"] = [int(r[1]) for r in rows] if world > 1 else int(rows[0][1])
+                    extra[f"{tag}_steps_accepted"] = [int(r[2]) for r in rows] if world > 1 else int(rows[0][2])
+                    extra[f"{tag}_steps_rejected"] = [int(r[3]) for r in rows] if world > 1 else int(rows[0][3])
+                finally:
+                    cnf.norm_group = prev
+            adaptive_reading("dopri5_adaptive", None)
+            extra["dopri5_adaptive_note"] = ("reference default: dopri5, rtol = atol = 1e-5 (flow_matching.py:78-84), NFE data-dependent; per-rank step control; "
+                                             "one warm-up solve, then one timed solve (max over ranks)")
+            if world > 1:
+                adaptive_reading("dopri5_adaptive_norm_group", True)
             if world == 1 and dev.type == "cuda":
                 # latents -> 256^2 images through the VAE decoder; outside the timed region and
                 # outside `value`, reported so the latent->latent figure can be read as an end-to-end one

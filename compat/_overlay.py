@@ -44,9 +44,15 @@ def load_shadowed(fullname, own_file):
         cand = os.path.join(p or ".", mod + ".py")
         if os.path.isfile(cand) and os.path.realpath(cand) != own:
             name = (pkg + "." if pkg else "") + "_ref_" + mod
+            if name in sys.modules:                 # one execution per process: nnet and nnet_ema get twins of ONE class object
+                return sys.modules[name]
             spec = importlib.util.spec_from_file_location(name, cand)
             m = importlib.util.module_from_spec(spec)
             sys.modules[name] = m
-            spec.loader.exec_module(m)
+            try:
+                spec.loader.exec_module(m)
+            except BaseException:
+                sys.modules.pop(name, None)         # no half-initialised module left behind
+                raise
             return m
     return None

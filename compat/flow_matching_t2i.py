@@ -18,11 +18,27 @@ class CNF(_CNF):
 
     def training_losses(self, x, context, sigma_min, **kwargs):
         net = _training.unwrap(self.net)
+        _training.note_training_step()
         twin = _training.reference_twin(net, _overlay)
         if twin is None:
             return super().training_losses(x, context, sigma_min, **kwargs)
         twin.train(net.training)                 # the script's nnet.train() / .eval() reaches the twin too
         return _training.flow_matching_loss(lambda t, xt: twin(xt, t, context=context, **kwargs)[0], x, sigma_min)
+
+    # weights edited through `.data` (the reference's EMA update) are invisible to the packed blob: repack after training steps
+    def decode(self, *a, **kw):
+        _training.refresh(self.net)
+        return super().decode(*a, **kw)
+
+    def encode(self, *a, **kw):
+        _training.refresh(self.net)
+        return super().encode(*a, **kw)
+
+    def decode_fixadp(self, *a, **kw):
+        _training.refresh(self.net)
+        return super().decode_fixadp(*a, **kw)
+
+    sample_ode = decode
 
 
 __all__ = ["CNF"]

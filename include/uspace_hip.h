@@ -13,7 +13,8 @@
  *     end of this header (not thread-safe: one measuring thread); (2) the LayerNorm-fold switch
  *     uspace_uvit_set_ln_fold / _get_ln_fold (atomic; default on); (3) per kernel, the set of devices on which it has
  *     been opted in to more than 64 KiB of dynamic LDS (atomic bit mask; any number of GPUs per process); (4) a
- *     mutex-protected cache of the parameter layout derived from each distinct uspace_uvit_config.
+ *     mutex-protected cache of the parameter layout derived from each distinct uspace_uvit_config; (5) the switch of the GEMM's
+ *     in-launch K-split tail uspace_gemm_set_sk / _get_sk (atomic; default on); (6) per device, whether it has the 256 CUs that form needs.
  * bf16 values cross the boundary as raw uint16_t (upper half of an IEEE fp32, RNE).
  */
 #ifndef USPACE_HIP_H
@@ -26,7 +27,7 @@
 extern "C" {
 #endif
 
-#define USPACE_ABI_VERSION 10
+#define USPACE_ABI_VERSION 11
 
 #define USPACE_OK 0
 #define USPACE_ERR_ARG (-1)         /* bad pointer / size / unsupported shape */
@@ -100,8 +101,25 @@ typedef struct uspace_gemm_ext {
      * stream at a time. */
     void* split_ws;
     size_t split_ws_bytes;
+    /* optional (round 6, ABI 11): workspace for the K-split TAIL of launches whose 256x256 tiles do not fill whole rounds of the 256
+     * CUs (proj / fc2 / skip_linear / qkv epilogues; e.g. M = 64 x 334 or 32 x 257 rows at N = 1024).  The whole rounds run as they are;
+     * every remaining tile is shared by 2 ... 4 workgroups of the SAME launch, each over a part of the K tiles, which exchange fp32
+     * partial sums through sk_ws and finish a part of the tile's rows each (fixed summation order: bit-identical run to run, no second
+     * kernel).  uspace_gemm_sk_ws_bytes(M, N, K) is the size it needs (0: the launch has no such tail).  sk_counters: 256 uint32,
+     * ALL ZERO when the launch starts (the kernel leaves counts behind: zero them again before the next use, or hand every launch its
+     * own 256).  Both NULL, or sk_ws too small: no tail (a producer of LayerNorm partial sums then takes plain 256x256 tiles).
+     * 16-byte aligned, must not alias any operand, one workspace serves one stream at a time. */
+    void* sk_ws;
+    size_t sk_ws_bytes;
+    void* sk_counters;
 } uspace_gemm_ext;
 USPACE_API size_t uspace_gemm_split_ws_bytes(int M, int N, int K);
+USPACE_API size_t uspace_gemm_sk_ws_bytes(int M, int N, int K);
+#define USPACE_GEMM_SK_COUNTERS 256
+/* process-wide switch of that form (A/B measurements): 1 = launches may take it (default), 0 = never, -1 = back to the default.
+ * uspace_gemm_plan_k / _part_slots_k / _sk_ws_bytes answer for the current setting; set it before sizing workspaces. */
+USPACE_API int uspace_gemm_set_sk(int mode);
+USPACE_API int uspace_gemm_get_sk(void);
 USPACE_API int uspace_gemm_bf16_ext(const uint16_t* A, int lda, const uint16_t* A2, int lda2, int K1,
                                     const uint16_t* W, int ldw, int M, int N, int K, int epi_flags,
                                     const float* bias, const float* resid_in, int ld_resid,

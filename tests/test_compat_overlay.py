@@ -166,6 +166,30 @@ def test_against_the_real_reference_tree(tmp_path):
         lt = CNF_T(net=net_t).training_losses(x, context=torch.randn(3, 5, 64), sigma_min=1e-4)
         lt.mean().backward()
         assert lt.shape == (3,) and net_t.context_embed.weight.grad is not None
+        # ---- ADVICE r5: (a) a wrapped network is refused (the loss would bypass the wrapper's forward: no gradient all-reduce under DDP)
+        class Wrapper(torch.nn.Module):
+            def __init__(self, m):
+                super().__init__(); self.module = m
+        try:
+            CNF(net=Wrapper(net)).training_losses(x, y=None, sigma_min=1e-4)
+            raise SystemExit('a wrapped network was accepted')
+        except NotImplementedError as e:
+            assert 'single-process' in str(e)
+        # (b) the twin follows the module's use_checkpoint; nnet and a second network (nnet_ema) get twins of ONE class object
+        net_ck = u.get_nnet('uvit', img_size=32, patch_size=2, in_chans=4, embed_dim=64, depth=2, num_heads=1, use_checkpoint=True)
+        CNF(net=net_ck).training_losses(x, y=None, sigma_min=1e-4).mean().backward()
+        assert net_ck._reference_twin.in_blocks[0].use_checkpoint is True and net._reference_twin.in_blocks[0].use_checkpoint is False
+        assert type(net_ck._reference_twin) is type(net._reference_twin)
+        # (c) weights edited through .data (the EMA update, tools/utils_uvit.py:109) are invisible to the packed blob: the overlay's decode
+        # forgets the blob of any network after a training step of the process
+        import _training
+        calls = []
+        net_ck.invalidate_packed = lambda: calls.append(1)
+        _training.refresh(net_ck); _training.refresh(net_ck)
+        assert calls == [1]
+        CNF(net=net).training_losses(x, y=None, sigma_min=1e-4)
+        _training.refresh(net_ck)
+        assert calls == [1, 1]
         print('ok')
     """ % (ROOT, COMPAT, ROOT))
     out = run([sys.executable, "-c", code], str(tmp_path), {"PYTHONDONTWRITEBYTECODE": "1"})
@@ -180,16 +204,7 @@ import numpy as np, torch
 sys.path.insert(0, %(root)r)
 from tests.test_multigpu_readiness import _FakeKernels
 from uspace_amd import _hip
-class Fake(_FakeKernels):
-    def uspace_ode_error_norm(self, y0, y1, ks, coefs, n, rtol, atol, numel, scratch, result, stream):
-        a0, a1 = self._arr(y0, numel), self._arr(y1, numel)
-        e = np.zeros(numel, np.float32)
-        for i in range(n):
-            e += np.float32(coefs[i]) * self._arr(ks[i], numel)
-        r = e / (atol + rtol * np.maximum(np.abs(a0), np.abs(a1)))
-        out = self._arr(result, 2)
-        out[1] = float((r.astype(np.float64) ** 2).sum()); out[0] = float(np.sqrt(out[1] / numel))
-        return 0
+Fake = _FakeKernels
 fake = Fake(_hip.lib())
 _hip.lib = lambda: fake
 _hip.require_device = lambda t, name="tensor": None

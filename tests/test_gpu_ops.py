@@ -729,3 +729,146 @@ def test_launch_recorder_reports_every_gemm_and_attention_launch(hip):
     assert n == 1 and 0.0 < ms < 50.0
     tf, gb, ghz = hip.prof_peaks(mfma_iters=2000, copy_bytes=1 << 26, copy_reps=2)
     assert 500.0 < tf < 2600.0 and 500.0 < gb < 8000.0 and 1.0 < ghz < 2.6     # the chip clocks to its power budget under the MFMA loop
+
+
+def _sk_ext(hip, ext, M, N, K):
+    """Give `ext` the workspace and a fresh set of zeroed arrival counters for the in-launch K-split tail; returns what must stay alive."""
+    need = hip.lib().uspace_gemm_sk_ws_bytes(M, N, K)
+    ws = torch.full((max(need // 4, 4),), float("nan"), device="cuda")
+    cnt = torch.zeros(256, dtype=torch.int32, device="cuda")
+    ext.sk_ws, ext.sk_ws_bytes, ext.sk_counters = hip.ptr(ws).value, need, hip.ptr(cnt).value
+    return need, ws, cnt
+
+
+@pytest.mark.parametrize("M,N,K,S,n_dp", [
+    (64 * 334, 1024, 4096, 3, 256),   # config 3 fc2: 83 tile rows + 8 strips = 332 tiles: one whole round + 76 tiles in 3 K parts (21 / 21 / 22 K tiles)
+    (32 * 257, 1024, 4096, 2, 0),     # config 5 fc2: 128 tiles + 2 strips, every tile in 2 K parts
+    (16 * 257, 1024, 4096, 4, 0),     # 64 tiles in 4 K parts (16 K tiles each)
+    (96 * 257, 1024, 4096, 2, 256),   # 384 tiles = one round + 128 tiles in 2 parts
+    (30 * 256 + 500, 1024, 4096, 2, 0),   # 31 tile rows of which the last holds 500 - 256 rows (more than one strip per tile row can take): no strips
+    (20 * 257 + 200, 1024, 4096, 3, 0),   # 20 tile rows + 14 strips: 80 tiles in 3 parts
+    (24 * 257, 1024, 4096, 0, 0),         # 96 tiles: two parts would leave a quarter of the CUs idle -- no tail
+    (64 * 334, 1024, 1024, 0, 0),     # K below 64 tiles: no tail (the exchange costs more than the K loop it saves, profiles/r06_sk_tail.md)
+])
+def test_gemm_k_split_tail_plain_epilogues(hip, M, N, K, S, n_dp):
+    """The in-launch K-split tail (round 6): launches whose 256x256 tiles do not fill whole rounds share each remaining tile between
+    S workgroups over K parts.  bias + residual in place + bf16 copy (fc2 of the out-blocks, libs/uvit.py:161) against the oracle
+    on sampled rows, against the same launch without the workspace, bit-identical over repeats on a NaN-poisoned workspace that is
+    reused with other data in between (a stale slab line would show)."""
+    import ctypes
+    lib = hip.lib()
+    plan = (ctypes.c_int * 8)()
+    assert lib.uspace_gemm_plan_k(M, N, K, 0, plan) == 0
+    need = lib.uspace_gemm_sk_ws_bytes(M, N, K)
+    if S == 0:
+        assert plan[0] != 6 and need == 0
+        return
+    assert plan[0] == 6 and (plan[1], plan[7]) == (S, n_dp), list(plan)
+    assert need > 0
+    rng = np.random.default_rng(M + N + K)
+    A = bf16_round(_rand(rng, M, K))
+    W = bf16_round(_rand(rng, N, K) * 0.05)
+    b = _rand(rng, N)
+    R = _rand(rng, M, N)
+    rows = np.unique(np.concatenate([rng.integers(0, M, 1200), np.arange(M - 300, M), np.arange(0, 300),
+                                     np.arange(16384 - 150, min(16384 + 150, M)) if M > 16384 else np.arange(0)]))
+    ref = C.linear(A[rows], W, b) + R[rows]
+    dA, dW, db, dR = to_dev(A, torch.bfloat16), to_dev(W, torch.bfloat16), to_dev(b), to_dev(R)
+    ws = torch.full((need // 4,), float("nan"), device="cuda")
+    other_A = to_dev(bf16_round(_rand(rng, M, K)), torch.bfloat16)
+    runs = []
+    for rep in range(3):
+        x = dR.clone()
+        xb = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        hip.gemm(dA, dW, bias=db, resid=x, out_f32=x, out_bf16=xb, sk_ws=ws)
+        runs.append((x, xb))
+        y = dR.clone()                                   # the same workspace with other operands in between
+        hip.gemm(other_A, dW, bias=db, resid=y, out_f32=y, sk_ws=ws)
+    torch.cuda.synchronize()
+    assert all(torch.equal(runs[0][0], r[0]) and torch.equal(runs[0][1], r[1]) for r in runs[1:])
+    x, xb = runs[0]
+    got = x.cpu().numpy()
+    np.testing.assert_allclose(got[rows], ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
+    assert rel_l2(got[rows], ref) < 1e-5
+    assert torch.equal(xb, x.to(torch.bfloat16))
+    # without the workspace: another tile form, the same numbers up to fp32 summation order -- on EVERY element
+    x0 = dR.clone()
+    hip.gemm(dA, dW, bias=db, resid=x0, out_f32=x0)
+    assert rel_l2(got, x0.cpu().numpy()) < 1e-6
+    assert float((x - x0).abs().max()) < 1e-3 * float(x0.abs().max())
+
+
+@pytest.mark.parametrize("M,D,Kp,N2", [
+    (64 * 334, 1024, 4096, 1024),   # config 3: fc2 of an in-block as producer (one round + 76 tiles in 3 K parts, strips)
+    (32 * 257, 1024, 4096, 3072),   # config 5: fc2 as producer (every tile in 2 K parts)
+    (16 * 257, 1024, 4096, 512),    # 4 K parts
+])
+def test_layernorm_folded_through_gemms_with_k_split_tail(hip, M, D, Kp, N2):
+    """test_layernorm_folded_through_gemms at the row counts where producers / consumers take the in-launch K-split tail: the
+    producer's centred copy and per-row partial sums (one stride of N / 256 slots per row for the whole launch), the consumer's
+    normalised output and the row means it publishes."""
+    import ctypes
+    lib = hip.lib()
+    plan = (ctypes.c_int * 8)()
+    assert lib.uspace_gemm_plan_k(M, D, Kp, 1, plan) == 0 and plan[0] == 6, list(plan)
+    rng = np.random.default_rng(M + D + N2 + Kp)
+    A = bf16_round(_rand(rng, M, Kp))
+    W = bf16_round(_rand(rng, D, Kp) * 0.05)
+    b = _rand(rng, D)
+    R = (_rand(rng, M, D) * 1.5 + _rand(rng, M, 1) * 2.0).astype(np.float32)
+    gam, bet = (_rand(rng, D) * 0.2 + 1.0).astype(np.float32), _rand(rng, D, scale=0.1)
+    W2 = (_rand(rng, N2, D) * 0.05).astype(np.float32)
+    b2 = _rand(rng, N2)
+    rows = np.unique(np.concatenate([rng.integers(0, M, 600), np.arange(300), np.arange(M - 300, M)]))
+    x_ref = C.linear(A[rows], W, b) + R[rows]
+    y_ref = C.linear(C.layernorm(x_ref, gam, bet, eps=1e-5), W2, b2)
+    c = R.mean(axis=1).astype(np.float32)
+    slots = lib.uspace_gemm_part_slots_k(M, D, Kp)
+    assert slots == D // 256
+    dA, dW, db = to_dev(A, torch.bfloat16), to_dev(W, torch.bfloat16), to_dev(b)
+    x = to_dev(R).clone()
+    xc = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+    part = torch.full((M, slots, 2), float("nan"), device="cuda")
+    dc = to_dev(c)
+    ext = hip.GemmExt(hip.ptr(dc).value, hip.ptr(xc).value, D, hip.ptr(part).value, None, 0, None, None, D, 1e-5)
+    keep = _sk_ext(hip, ext, M, D, Kp)
+    assert keep[0] > 0
+    flags = hip.EPI_BIAS | hip.EPI_RESIDUAL | hip.EPI_OUT_F32 | hip.EPI_CEN_OUT
+    rc = lib.uspace_gemm_bf16_ext(hip.ptr(dA), Kp, None, 0, Kp, hip.ptr(dW), Kp, M, D, Kp, flags, hip.ptr(db), hip.ptr(x), D,
+                                  hip.ptr(x), D, None, 0, ctypes.byref(ext), hip.stream_ptr())
+    assert rc == 0
+    xg = x.cpu().numpy()
+    np.testing.assert_allclose(xg[rows], x_ref, rtol=1e-3, atol=2e-3)
+    assert torch.equal(xc, (x - dc[:, None]).to(torch.bfloat16))
+    pgr = part.cpu().numpy()
+    assert np.isfinite(pgr).all()
+    pg = pgr.astype(np.float64).sum(axis=1)
+    cen = xg.astype(np.float64) - c[:, None]
+    np.testing.assert_allclose(pg[:, 0], cen.sum(1), rtol=1e-4, atol=2e-2)
+    np.testing.assert_allclose(pg[:, 1], (cen ** 2).sum(1), rtol=1e-4)
+    # the same producer without the workspace: plain 256x256 tiles, the same partial-sum stride
+    x1 = to_dev(R).clone()
+    xc1 = torch.empty_like(xc)
+    part1 = torch.full((M, slots, 2), float("nan"), device="cuda")
+    ext1 = hip.GemmExt(hip.ptr(dc).value, hip.ptr(xc1).value, D, hip.ptr(part1).value, None, 0, None, None, D, 1e-5)
+    rc = lib.uspace_gemm_bf16_ext(hip.ptr(dA), Kp, None, 0, Kp, hip.ptr(dW), Kp, M, D, Kp, flags, hip.ptr(db), hip.ptr(x1), D,
+                                  hip.ptr(x1), D, None, 0, ctypes.byref(ext1), hip.stream_ptr())
+    assert rc == 0
+    assert rel_l2(xg, x1.cpu().numpy()) < 1e-6
+    np.testing.assert_allclose(part1.cpu().numpy().astype(np.float64).sum(axis=1), pg, rtol=1e-4, atol=2e-2)
+    # consumer
+    W2g = bf16_round(W2 * gam[None, :])
+    bias2 = (b2 + W2 @ bet).astype(np.float32)
+    colsum = W2g.sum(axis=1).astype(np.float32)
+    y = torch.empty(M, N2, dtype=torch.bfloat16, device="cuda")
+    cbuf = dc.clone()                                          # published IN PLACE, as the forward does (c <- c + d)
+    dW2, dbias2, dcs = to_dev(W2g, torch.bfloat16), to_dev(bias2), to_dev(colsum)
+    ext2 = hip.GemmExt(hip.ptr(cbuf).value, None, 0, None, hip.ptr(part).value, slots, hip.ptr(dcs).value, hip.ptr(cbuf).value, D, 1e-5)
+    keep2 = None
+    rc = lib.uspace_gemm_bf16_ext(hip.ptr(xc), D, None, 0, D, hip.ptr(dW2), D, M, N2, D, hip.EPI_BIAS | hip.EPI_OUT_BF16 | hip.EPI_LN_IN,
+                                  hip.ptr(dbias2), None, 0, None, 0, hip.ptr(y), N2, ctypes.byref(ext2), hip.stream_ptr())
+    assert rc == 0
+    yg = y.float().cpu().numpy()[rows]
+    assert rel_l2(yg, y_ref) < 4e-3, rel_l2(yg, y_ref)
+    np.testing.assert_allclose(cbuf.cpu().numpy(), xg.mean(axis=1), rtol=1e-4, atol=1e-4)
+    del keep, keep2

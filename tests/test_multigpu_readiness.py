@@ -204,6 +204,17 @@ class _FakeKernels:
         self._arr(out, numel)[:] = acc
         return 0
 
+    def uspace_ode_error_norm(self, y0, y1, ks, coefs, n, rtol, atol, numel, scratch, result, stream):
+        a0, a1 = self._arr(y0, numel), self._arr(y1, numel)
+        e = np.zeros(numel, np.float32)
+        for i in range(n):
+            e += np.float32(coefs[i]) * self._arr(ks[i], numel)
+        r = e / (atol + rtol * np.maximum(np.abs(a0), np.abs(a1)))
+        out = self._arr(result, 2)
+        out[1] = float((r.astype(np.float64) ** 2).sum())
+        out[0] = float(np.sqrt(out[1] / numel))
+        return 0
+
     def uspace_prof_all_begin(self, n):
         return 0
 
@@ -304,6 +315,15 @@ def test_bench_main_runs_end_to_end_on_two_gloo_ranks(tmp_path):
     assert [r["rank"] for r in mg["ranks_seen"]] == [0, 1] and [r["local_rank"] for r in mg["ranks_seen"]] == [0, 1]
     assert len({r["pid"] for r in mg["ranks_seen"]}) == 2 and len(mg["per_rank_median_ms"]) == 2 and len(mg["per_rank_wall_s"]) == 2
     assert line["ms_per_step"] * 2e-3 == pytest.approx(max(mg["per_rank_wall_s"]), rel=1e-9)             # MAX over ranks
-    # every rank ran its own solves: warm-up + 2 timed + (rank 0: the recorded extra solve) + 2 Euler solves of 4 steps
+    # the reference-default sampler's reading (adaptive dopri5, rtol = atol = 1e-5): per-rank step control and the group-controlled form,
+    # one entry per rank each; under group control every rank takes the same steps
+    for tag in ("dopri5_adaptive", "dopri5_adaptive_norm_group"):
+        nfe, acc, rej = line[f"{tag}_nfe"], line[f"{tag}_steps_accepted"], line[f"{tag}_steps_rejected"]
+        assert len(nfe) == len(acc) == len(rej) == 2 and line[f"{tag}_images_per_sec"] > 0
+        assert all(n == 2 + 6 * (a + r) for n, a, r in zip(nfe, acc, rej)) and min(acc) >= 2      # 2 evaluations pick the first step
+    assert len(set(line["dopri5_adaptive_norm_group_nfe"])) == 1
+    # every rank ran its own solves: warm-up + 2 timed + (rank 0: the recorded extra solve) + 2 Euler solves of 4 steps + 2 x 2 adaptive solves
     f0, f1 = int(open(tmp_path / "forwards0.txt").read()), int(open(tmp_path / "forwards1.txt").read())
-    assert f1 == 3 * 25 + 2 * 4 and f0 == f1 + 25
+    adaptive1 = 2 * line["dopri5_adaptive_nfe"][1] + 2 * line["dopri5_adaptive_norm_group_nfe"][1]
+    adaptive0 = 2 * line["dopri5_adaptive_nfe"][0] + 2 * line["dopri5_adaptive_norm_group_nfe"][0]
+    assert f1 == 3 * 25 + 2 * 4 + adaptive1 and f0 == 4 * 25 + 2 * 4 + adaptive0

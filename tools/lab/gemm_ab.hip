@@ -104,6 +104,15 @@ int main(int argc, char** argv) {
     uint16_t *dA, *dA2, *dW, *dO[2], *dCen[2];
     float *db, *dR, *dF[2], *dPin, *dPout[2], *dC, *dCout[2], *dCs, *dWs;
     const size_t ws_bytes = (size_t)8 * M * D * 4;   // K-split workspace (ignored by libraries older than ABI 5)
+    // in-launch K-split tail (ABI 11; older libraries never read these fields): slabs + a fresh set of 256 zeroed counters per launch
+    char* dSk;
+    unsigned* dCnt;
+    const size_t sk_bytes = (size_t)80 << 20;
+    constexpr int NCNT = 1024;                       // counter sets, zeroed before every timed round
+    int cnt_next = 0;
+    HCHECK(hipMalloc(&dSk, sk_bytes));
+    HCHECK(hipMalloc(&dCnt, (size_t)NCNT * 256 * 4));
+    HCHECK(hipMemset(dCnt, 0, (size_t)NCNT * 256 * 4));
     HCHECK(hipMalloc(&dA, nA * 2));
     HCHECK(hipMalloc(&dA2, (size_t)M * D * 2));
     HCHECK(hipMalloc(&dW, nW * 2));
@@ -158,6 +167,9 @@ int main(int argc, char** argv) {
             ext.eps = 1e-5f;
             ext.split_ws = dWs;
             ext.split_ws_bytes = ws_bytes;
+            ext.sk_ws = dSk;
+            ext.sk_ws_bytes = sk_bytes;
+            ext.sk_counters = dCnt + (size_t)(cnt_next++ % NCNT) * 256;
             if (s.flags & C_) { ext.row_c = dC; ext.out_cen = dCen[v]; ext.ld_cen = D; ext.part_out = dPout[v]; }
             if (s.flags & L_) { ext.part_in = dPin; ext.np_in = 4; ext.colsum = dCs; ext.row_c = dC; ext.c_out = dCout[v]; }
             if (s.flags & K_) { ext.row_add = dC; ext.col_add = dCs; }
@@ -168,6 +180,8 @@ int main(int argc, char** argv) {
                                      &ext, nullptr);
             if (rc) { fprintf(stderr, "%s rc %d\n", s.name, rc); exit(1); }
         };
+        HCHECK(hipMemset(dCnt, 0, (size_t)NCNT * 256 * 4));
+        cnt_next = 0;
         for (int v = 0; v < 2; ++v) run(v);
         HCHECK(hipDeviceSynchronize());
         // outputs agree?
@@ -204,6 +218,9 @@ int main(int argc, char** argv) {
         std::vector<float> t[2];
         for (int r = 0; r < rounds; ++r)
             for (int v = 0; v < 2; ++v) {
+                HCHECK(hipMemsetAsync(dCnt, 0, (size_t)NCNT * 256 * 4, 0));
+                cnt_next = 0;
+                if (reps + 1 > NCNT) { fprintf(stderr, "reps > %d counter sets\n", NCNT - 1); return 2; }
                 run(v);
                 HCHECK(hipEventRecord(e0, 0));
                 for (int i = 0; i < reps; ++i) run(v);

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("USPACE_HIP_LIB") or _DEFAULT_LIB
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_OUT_BF16 = 1, 2, 4, 8, 16
 EPI_CEN_OUT, EPI_LN_IN, EPI_RANK1 = 32, 64, 128          # uspace_gemm_bf16_ext only (LayerNorm folded through the GEMMs)
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _ERR = {-1: "USPACE_ERR_ARG", -2: "USPACE_ERR_LAUNCH", -3: "USPACE_ERR_WORKSPACE"}
 
@@ -55,7 +55,8 @@ class GemmExt(ctypes.Structure):
                 ("part_out", ctypes.c_void_p), ("part_in", ctypes.c_void_p), ("np_in", ctypes.c_int),
                 ("colsum", ctypes.c_void_p), ("c_out", ctypes.c_void_p), ("norm_dim", ctypes.c_int), ("eps", ctypes.c_float),
                 ("row_add", ctypes.c_void_p), ("col_add", ctypes.c_void_p),
-                ("split_ws", ctypes.c_void_p), ("split_ws_bytes", ctypes.c_size_t)]
+                ("split_ws", ctypes.c_void_p), ("split_ws_bytes", ctypes.c_size_t),
+                ("sk_ws", ctypes.c_void_p), ("sk_ws_bytes", ctypes.c_size_t), ("sk_counters", ctypes.c_void_p)]
 
 
 _P, _I, _L, _F, _SZ = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
@@ -69,6 +70,9 @@ SIGNATURES = {
     "uspace_gemm_part_slots": (_I, [_I, _I]),
     "uspace_gemm_part_slots_k": (_I, [_I, _I, _I]),
     "uspace_gemm_split_ws_bytes": (_SZ, [_I, _I, _I]),
+    "uspace_gemm_sk_ws_bytes": (_SZ, [_I, _I, _I]),
+    "uspace_gemm_set_sk": (_I, [_I]),
+    "uspace_gemm_get_sk": (_I, []),
     "uspace_fold_layernorm": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "uspace_center_rows": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "uspace_uvit_set_ln_fold": (_I, [_I]),
@@ -156,6 +160,9 @@ def lib():
         env = os.environ.get("USPACE_LN_FOLD")
         if env is not None and env != "":
             L.uspace_uvit_set_ln_fold(0 if env[0] == "0" else 1)
+        env = os.environ.get("USPACE_GEMM_SK")   # ... USPACE_GEMM_SK=0 switches the GEMM's in-launch K-split tail off
+        if env is not None and env != "":
+            L.uspace_gemm_set_sk(0 if env[0] == "0" else 1)
         _lib = L
     return _lib
 
@@ -195,9 +202,10 @@ def require_device(t, name="tensor"):
 # ------------------------------------------------------------------------------------------
 # thin operator wrappers (used by the parity tests and by the solver); tensors are torch CUDA
 # ------------------------------------------------------------------------------------------
-def gemm(A, W, *, A2=None, bias=None, resid=None, gelu=False, out_f32=None, out_bf16=None, split_ws=None):
+def gemm(A, W, *, A2=None, bias=None, resid=None, gelu=False, out_f32=None, out_bf16=None, split_ws=None, sk_ws=None):
     """acc = [A|A2] @ W^T with fused epilogue; A/A2/W are torch.bfloat16, returns (out_f32, out_bf16).  split_ws: an optional
-    fp32 workspace tensor (uspace_gemm_split_ws_bytes) that allows the K-split form of small launches."""
+    fp32 workspace tensor (uspace_gemm_split_ws_bytes) that allows the K-split form of small launches.  sk_ws: an optional
+    workspace tensor (uspace_gemm_sk_ws_bytes) that allows the in-launch K-split tail; its 256 arrival counters are made here."""
     require_device(A, "A")
     M, K1 = A.shape
     N, K = W.shape
@@ -217,11 +225,18 @@ def gemm(A, W, *, A2=None, bias=None, resid=None, gelu=False, out_f32=None, out_
             ptr(bias), ptr(resid), resid.stride(0) if resid is not None else 0,
             ptr(out_f32), out_f32.stride(0) if out_f32 is not None else 0,
             ptr(out_bf16), out_bf16.stride(0) if out_bf16 is not None else 0)
-    if split_ws is not None:
-        require_device(split_ws, "split_ws")
+    if split_ws is not None or sk_ws is not None:
         ext = GemmExt()
-        ext.split_ws = ptr(split_ws).value
-        ext.split_ws_bytes = split_ws.numel() * split_ws.element_size()
+        if split_ws is not None:
+            require_device(split_ws, "split_ws")
+            ext.split_ws = ptr(split_ws).value
+            ext.split_ws_bytes = split_ws.numel() * split_ws.element_size()
+        if sk_ws is not None:
+            require_device(sk_ws, "sk_ws")
+            counters = torch.zeros(256, dtype=torch.int32, device=sk_ws.device)
+            ext.sk_ws = ptr(sk_ws).value
+            ext.sk_ws_bytes = sk_ws.numel() * sk_ws.element_size()
+            ext.sk_counters = ptr(counters).value
         rc = lib().uspace_gemm_bf16_ext(*args, ctypes.byref(ext), stream_ptr())
     else:
         rc = lib().uspace_gemm_bf16(*args, stream_ptr())

@@ -48,6 +48,8 @@ using namespace usgemm;
 #ifndef USPACE_CHAIN
 #define USPACE_CHAIN 0
 #endif
+// bytes of one K part's accumulators of one shared tile (SK): 1 KiB per wave and 16 x 16 sub-tile, strip sub-tiles included
+constexpr size_t sk_slab_bytes(int BM, int BN, bool xtra) { return (size_t)((BM / 16) * (BN / 16) + (xtra ? BN / 16 : 0)) * 1024; }
 constexpr double TALL_COST = 0.60;   // one round of 256x128 tiles in units of a round of 256x256 tiles (measured, profiles/r02_gemm_ablation.md)
 constexpr int ROW_BYTES = 128;
 
@@ -114,7 +116,7 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int FLAGS, bool XTRA, int NST = 2>
+template <int BM, int BN, int WM, int WN, int FLAGS, bool XTRA, int NST = 2, bool SK = false>
 // (second launch bound = waves per SIMD: the 4-wave 128x128 form shares a CU with a second workgroup, so its waves must
 // fit 256 registers; one instantiation had grown to 264)
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 64)) ? 2 : 1) void gemm_kernel(const GemmArgs g) {
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
                   "the ring form: raw fp32 partial sums of a K range (K-split), or the 64 x 64 tiles with any epilogue");
     constexpr int IPT = ISSUES_A + ISSUES_W;    // LDS-DMA instructions per wave and K tile
     static_assert((NST - 1) * IPT < 64, "vmcnt is a 6-bit counter");
+    static_assert(!SK || (NST == 2 && WM * WN == 8), "the in-launch K-split tail is written for the 8-wave two-stage forms (one workgroup per CU)");
 
     // LayerNorm folding: per-row values of this tile (main rows, then the 16 strip rows) are fetched at kernel start
     // (their latency sits under the first tile) and parked behind the stage buffers: consumer (d, rstd), producer
@@ -159,8 +162,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
     //      instead of 18 for a 2 x 16 strip) and keeps its A row-block across rounds.
     const int nwg = g.tiles_m * g.tiles_n;
     int tile_m, tile_n;
+    // SK: blocks >= sk_first share tiles -- sk_S of them per tile, each over its own K range.  Block sk_first + u works on tile
+    // sk_first + 8 * ((u >> 3) / S) + (u & 7), K part (u >> 3) % S: the S parts of a tile are 8 block ids apart, i.e. (block b runs on
+    // XCD b % 8 -- observed, speed only) they exchange their partial sums inside one XCD; the last group of 8 tiles may be padding.
+    int sk_tile = -1, sk_split = 0;
     {
-        const int b = blockIdx.x;
+        int b = blockIdx.x;
+        if constexpr (SK) {
+            if (b >= g.sk_first) {
+                const int u = b - g.sk_first, v = u >> 3;
+                sk_split = v % g.sk_S;
+                sk_tile = (v / g.sk_S) * 8 + (u & 7);
+                b = g.sk_first + sk_tile;
+                if (b >= nwg) return;
+            }
+        }
         const int xcd = b & 7, idx = b >> 3;
         const int n_super = nwg >> 5;
         if ((g.tiles_m & 7) == 0 && (g.tiles_n & 3) == 0 && (n_super & 7) == 0) {
@@ -232,7 +248,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         const bf16_t* b = (gA2 && sl > 0) ? gA2 : gA;
         return (const char*)(b + (long)g.slab_shift[sl] * lda_l + kin);
     };
-    const int kt0 = NST > 2 ? (int)blockIdx.y * g.nk_split : 0;   // ring form: this workgroup's K range starts here
+    // ring form: this workgroup's K range starts here; SK: K part sk_split of sk_S (balanced to a K tile)
+    const int kt0 = NST > 2 ? (int)blockIdx.y * g.nk_split : (SK && sk_tile >= 0) ? sk_split * (g.K / BK) / g.sk_S : 0;
     float* const out_f32 = NST > 2 ? g.out_f32 + (size_t)blockIdx.y * g.split_stride : g.out_f32;
     // LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... offen lds): the descriptor is built from the wave-uniform
     // base of this K tile, the per-lane part is ONE 32-bit VGPR offset per instruction, M0 carries the LDS address.  (The flat
@@ -274,7 +291,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
 
     f32x4 acc[TM][TN];
     f32x4 xacc[XTRA ? XN : 1];
-    if constexpr (FLAGS & USPACE_EPI_RESIDUAL) {
+    if ((FLAGS & USPACE_EPI_RESIDUAL) != 0 && (!SK || sk_split == 0)) {   // (SK: K part 0 starts from the residual, the others from zero)
         // x += ... : the residual IS the accumulator's initial value.  Its fp32 read (the HBM-bound part of
         // the proj / fc2 epilogue) is issued here and lands while the first K tiles stream in.
         // Rows / columns outside the problem are clamped (their accumulators are never stored).
@@ -364,7 +381,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
 
     // does this workgroup own a strip?  A run-time fact here; the two-stage K loop below is compiled twice (X_ON a constant in each copy)
     const bool X_ON = has_x;
-    const int nk = NST > 2 ? g.nk_split : g.K / BK;
+    const int nk = NST > 2 ? g.nk_split : (SK && sk_tile >= 0) ? (sk_split + 1) * (g.K / BK) / g.sk_S - kt0 : g.K / BK;
     // LayerNorm folding: thread t fetches the per-row values of tile row t (main rows, then the 16 strip rows) right
     // behind the first LDS-DMA stages -- their latency overlaps the first tile's -- and parks them in LDS after the barrier
     // (ring form: before the stages, so that the counted wait for the first tile covers them)
@@ -384,7 +401,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
 #pragma unroll
                     for (int q = 0; q < 8; ++q)
                         pr[q] = q < g.np_in ? *(const float2*)(g.part_in + ((size_t)m * g.np_in + q) * 2) : make_float2(0.f, 0.f);
-                    if (n0 == 0 && g.c_out) rc_v = g.row_c[m];
+                    if (n0 == 0 && g.c_out && sk_split == 0) rc_v = g.row_c[m];
                 } else {
                     rc_v = g.row_c[m];
                     if constexpr (RK1) ra_v = g.row_add[m];
@@ -433,7 +450,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
                     }
                     const float d = s1 * g.inv_d;
                     v = make_float2(d, rsqrtf(fmaxf(s2 * g.inv_d - d * d, 0.f) + g.eps));
-                    if (n0 == 0 && g.c_out) g.c_out[rv_m] = rc_v + d;     // N tile 0 publishes the row mean
+                    if (n0 == 0 && g.c_out && sk_split == 0) g.c_out[rv_m] = rc_v + d;     // N tile 0 publishes the row mean
                 } else {
                     v = make_float2(rc_v, ra_v);
                 }
@@ -691,6 +708,99 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
 #undef MMA
 #undef MMA_X
 
+    // ---- SK: the K parts of a shared tile exchange their partial sums.  Part p finishes the row sub-tiles [own_lo, own_hi) of every wave
+    //      (and part 0 the strip): it publishes the others' rows of its accumulators -- 16-byte write-through (sc1) stores in register
+    //      order, 1 KiB per wave and sub-tile --, drains, arrives at the tile's counter, waits for all sk_S arrivals (relaxed polls by one
+    //      lane, then ONE agent-scope acquire) and adds the partners' values for its own rows in part order: p0 + p1 + ..., whoever
+    //      arrives when -- bit-identical run to run.  All parts of all shared tiles are resident together (<= 256 workgroups of one per
+    //      CU, the whole-tile workgroups in front of them never wait), so the wait ends; a poll count that cannot be reached traps.
+    int own_lo = 0, own_hi = TM;
+    if constexpr (SK) {
+        if (sk_tile >= 0) {
+            const int S = g.sk_S;
+            own_lo = sk_split * TM / S;
+            own_hi = (sk_split + 1) * TM / S;
+            constexpr int WSLOTS = TM * TN + (XTRA ? XN : 0);                 // 1-KiB pieces per wave
+            constexpr size_t SLAB_BYTES = (size_t)WM * WN * WSLOTS * 1024;    // one part's accumulators of one tile
+            static_assert(SLAB_BYTES == sk_slab_bytes(BM, BN, XTRA), "host and kernel agree on the slab size");
+            char* const slabs = (char*)g.sk_ws + (size_t)sk_tile * S * SLAB_BYTES;
+            const uint32_t lane_off = (uint32_t)(wave * WSLOTS) * 1024u + (uint32_t)lane * 16u;
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+            {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(slabs + (size_t)sk_split * SLAB_BYTES), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    if (i >= own_lo && i < own_hi) continue;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[i][j]), rs, lane_off + (uint32_t)(i * TN + j) * 1024u, 0, 16);
+                }
+                if constexpr (XTRA) {
+                    if (has_x && sk_split != 0) {
+#pragma unroll
+                        for (int j = 0; j < XN; ++j)
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, xacc[j]), rs, lane_off + (uint32_t)(TM * TN + j) * 1024u, 0, 16);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every storing wave drains its write-through stores ...
+            __syncthreads();                                    // ... before the one arrival
+            if (tid == 0) {
+                unsigned* const cnt = g.sk_cnt + sk_tile;
+                __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned polls = 0;
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)S) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++polls > (1u << 23)) __builtin_trap();   // seconds: a partner that never ran (not a timing matter)
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            // (one row sub-tile at a time: requesting the partners' values of several sub-tiles before the first add -- 16 to 24 loads of 16
+            // bytes per lane -- was tried and spills next to the 128 accumulator registers)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (i < own_lo || i >= own_hi) continue;
+                f32x4 pv[4][TN];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (t < S && t != sk_split) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            pv[t][j] = *(const f32x4*)(slabs + (size_t)t * SLAB_BYTES + lane_off + (uint32_t)(i * TN + j) * 1024u);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) pv[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    // p0 + p1 + ... in part order, this part's own accumulator at its place
+                    f32x4 v = sk_split == 0 ? acc[i][j] : pv[0][j];
+#pragma unroll
+                    for (int t = 1; t < 4; ++t) {
+                        const f32x4 w = v + (t == sk_split ? acc[i][j] : pv[t][j]);
+                        v = t < S ? w : v;
+                    }
+                    acc[i][j] = v;
+                }
+            }
+            if constexpr (XTRA) {
+                if (has_x && sk_split == 0) {
+#pragma unroll
+                    for (int j = 0; j < XN; ++j) {
+                        f32x4 v = xacc[j];
+#pragma unroll
+                        for (int t = 1; t < 4; ++t)
+                            if (t < S) v += *(const f32x4*)(slabs + (size_t)t * SLAB_BYTES + lane_off + (uint32_t)(TM * TN + j) * 1024u);
+                        xacc[j] = v;
+                    }
+                }
+            }
+        }
+    }
+    const bool own_x = !SK || sk_split == 0;      // the strip rows belong to K part 0
+
     // ---- epilogue: lane holds, for sub-tile (i,j), row m = ..+fr and columns n = ..+4*fq+{0,1,2,3}
     if constexpr (!EARLY_EPI) load_epi_consts();
     float ps1 = 0.f, ps2 = 0.f;   // producer: running partial sums of the row being emitted
@@ -788,6 +898,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         const int nw = n0 + wn * (BN / WN) + (fq & 1) * 16 + (fq >> 1) * 8;   // this lane's column in a widened pair (+ 32 per pair)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            if (SK && (i < own_lo || i >= own_hi)) continue;     // (SK: another K part finishes these rows)
             const int m = m0 + wm * (BM / WM) + i * 16 + fr;
             row_begin(i);
             // the TN vectors of a row go through the activation together (TN x 4 independent chains)
@@ -826,6 +937,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
     } else {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            if (SK && (i < own_lo || i >= own_hi)) continue;
             const int m = m0 + wm * (BM / WM) + i * 16 + fr;
             const bool vrow = m < m_lim;
             row_begin(i);
@@ -842,7 +954,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
     }
     if constexpr (XTRA) {
         const int m = x0 + fr;
-        const bool vrow = fr < xr && m < g.M;
+        const bool vrow = fr < xr && m < g.M && own_x;
         row_begin(TM);
         if (vrow) {
 #pragma unroll
@@ -865,7 +977,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         for (int t = tid; t < BM + (XTRA ? 16 : 0); t += THREADS) {
             const bool strip = t >= BM;
             const int m = strip ? x0 + (t - BM) : m0 + t;
-            const bool ok = strip ? ((t - BM) < xr && m < g.M) : (m < m_lim);
+            bool ok = strip ? ((t - BM) < xr && m < g.M) : (m < m_lim);
+            if constexpr (SK) {
+                const int it = (t % (BM / WM)) >> 4;          // the row's sub-tile index inside its wave row
+                ok = ok && (strip ? own_x : (it >= own_lo && it < own_hi));
+            }
             if (!ok) continue;
             float a = 0.f, bq = 0.f;
             const int nslot = strip ? RSLOTS : WN;
@@ -900,6 +1016,90 @@ int launch(const GemmArgs& a, hipStream_t s, int wg_per_round) {
     us_rec_end(rec, s);
     US_CHECK_LAUNCH();
     return USPACE_OK;
+}
+
+// ---- K-split tail inside one launch ("SK"; round 6, profiles/r06_sk_tail.md).  A launch whose 256x256 tiles do not fill whole rounds
+// of the 256 CUs pays a full round for the rest (M = 64 x 334 rows, N = 1024: 332 tiles = 1.30 rounds; the 192x256 form made it 2 x 0.8)
+// or half-fills the chip (M = 32 x 257: 128 tiles; the 256x128 form is ingest-bound at 0.60 of a round for half of one).  Here the
+// whole rounds run as they are and each of the remaining tiles is shared by S = 2 ... 4 workgroups of the SAME launch, each over 1 / S
+// of the K tiles, which then exchange partial sums and finish 1 / S of the tile's rows each (kernel: "SK").  One stride of LayerNorm
+// partial sums per launch, so producers can take it (the two-launch split form could not).
+struct SkPlan {
+    Plan rows;
+    int tiles_n, n_dp, n_sk, groups, S;
+};
+// Measured (profiles/r06_sk_tail.md): the exchange moves every shared tile's fp32 sums through the memory side once (256 KiB per tile
+// out and back in: 67 MB for 128 tiles, beside the 100-160 MB such a launch moves anyway) and costs 14-25 us whatever K is; what it buys
+// is 1 - 1/S of the K loop.  It pays for K = 4096 (64 K tiles: fc2 of U-ViT-L -- 0.84 at 16 x 257 rows, 0.96-0.99 at 32 x 257 / 64 x 334 /
+// 96 x 257) and loses 4-40 % for K <= 2048 (proj, skip_linear, qkv), so the plan exists for K loops of 64 tiles or more only.
+constexpr int SK_MIN_NK = 64;           // K tiles of the whole K loop at the least
+constexpr int SK_MIN_KT = 16;           // ... and per part
+constexpr double SK_FIXED = 0.10;       // the exchange, in units of a round of 256x256 tiles of such a K loop (14 of 141 us)
+std::atomic<int> g_sk_on{1};            // process-wide switch (include/uspace_hip.h: uspace_gemm_set_sk)
+inline bool sk_plan(int M, int N, int K, SkPlan* out) {
+    if (!g_sk_on.load(std::memory_order_relaxed)) return false;
+    if (M < 256 || N < 256 || (N & 255) || K % BK || K / BK < SK_MIN_NK) return false;     // whole 256-column tiles (wide stores, interior epilogue)
+    const int tn = N / 256, tm = M / 256, rem = M - tm * 256, nk = K / BK;
+    SkPlan p;
+    p.tiles_n = tn;
+    if (rem == 0) p.rows = Plan{tm, M, 0};
+    else if (rem <= 16 * tm) p.rows = Plan{tm, tm * 256, us_cdiv(rem, 16)};
+    else p.rows = Plan{tm + 1, M, 0};
+    const int T = p.rows.tiles_m * tn;
+    p.n_dp = T / 256 * 256;
+    p.n_sk = T - p.n_dp;
+    if (p.n_sk == 0) return false;
+    p.groups = us_cdiv(p.n_sk, 8);
+    p.S = std::min(std::min(4, 256 / (p.groups * 8)), nk / SK_MIN_KT);
+    if (p.S < 2) return false;
+    // two parts per tile on fewer than 7/8 of the CUs lose to the 256x128 form (24 x 257 rows: 96 tiles x 2, +5-7 %)
+    if (p.S == 2 && p.groups * 8 * p.S < 224) return false;
+    *out = p;
+    return true;
+}
+inline double sk_cost(const SkPlan& p) { return (p.n_dp / 256 + 1.0 / p.S) * strip_factor(p.rows, 256) + SK_FIXED; }
+inline size_t sk_ws_need(const SkPlan& p) { return (size_t)p.groups * 8 * p.S * sk_slab_bytes(256, 256, p.rows.n_strip > 0); }
+static_assert(USPACE_GEMM_SK_COUNTERS >= 128, "S >= 2 parts of at most 128 shared tiles");
+
+// the device must hold every shared-tile workgroup at once (one per CU): checked once per device
+inline bool sk_device_ok() {
+    static std::atomic<int> state[64];  // 0 unknown, 1 ok, 2 no
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    int st = state[dev].load(std::memory_order_relaxed);
+    if (st == 0) {
+        int cus = 0;
+        st = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 256) ? 1 : 2;
+        state[dev].store(st, std::memory_order_relaxed);
+    }
+    return st == 1;
+}
+
+template <int FLAGS>
+int launch_sk(const GemmArgs& a, hipStream_t s, const SkPlan& p) {
+    GemmArgs g = a;
+    g.tiles_n = p.tiles_n;
+    g.tiles_m = p.rows.tiles_m;
+    g.m_main = p.rows.m_main;
+    g.n_strip = p.rows.n_strip;
+    g.sk_first = p.n_dp;
+    g.sk_S = p.S;
+    const int rec = us_rec_begin(US_REC_GEMM, FLAGS, g.M, g.N, g.K, s);
+    const dim3 grid(p.n_dp + p.groups * 8 * p.S), block(512);
+    if (p.rows.n_strip > 0) hipLaunchKernelGGL((gemm_kernel<256, 256, 2, 4, FLAGS, true, 2, true>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_kernel<256, 256, 2, 4, FLAGS, false, 2, true>), grid, block, 0, s, g);
+    us_rec_end(rec, s);
+    US_CHECK_LAUNCH();
+    return USPACE_OK;
+}
+// the epilogues the SK form is instantiated for: fc2 (the one launch of a block with K >= 4096) as producer of a folded LayerNorm
+// (in-blocks), with the raw bf16 copy (mid / out blocks) and plain (last block; the unfolded path)
+// -- and every other producer epilogue, because uspace_gemm_part_slots_k answers for "a producer with this K" without knowing which
+constexpr bool sk_flags(int f) {
+    constexpr int B_ = USPACE_EPI_BIAS, R_ = USPACE_EPI_RESIDUAL, F_ = USPACE_EPI_OUT_F32, H_ = USPACE_EPI_OUT_BF16, C_ = USPACE_EPI_CEN_OUT,
+                  K_ = USPACE_EPI_RANK1;
+    return f == (C_ | B_ | R_ | F_) || f == (B_ | R_ | F_ | H_) || f == (B_ | R_ | F_) || f == (C_ | B_ | R_ | F_ | H_) || f == (C_ | B_ | F_) ||
+           f == (K_ | C_ | B_ | F_);
 }
 
 #if USPACE_CHAIN
@@ -1033,7 +1233,8 @@ int launch_big(const GemmArgs& a, hipStream_t s) {
     return launch<256, 256, 2, 4, FLAGS>(a, s, 256);
 }
 
-enum TileChoice { TILE_BIG = 0, TILE_MID = 1, TILE_SMALL = 2, TILE_SPLIT = 3, TILE_TALL = 4, TILE_TINY = 5 };
+enum TileChoice { TILE_BIG = 0, TILE_MID = 1, TILE_SMALL = 2, TILE_SPLIT = 3, TILE_TALL = 4, TILE_TINY = 5, TILE_SK = 6 };
+struct TileCosts { double c[5]; };      // the cost model's figure for each of the first five forms (1e30: not applicable)
 
 // Four tile configurations, chosen by a round-count cost model (unit: one round of 256x256 tiles):
 //   256x256, 8 waves (2x4), ~130 KiB LDS, 1 workgroup/CU     cost 1.00 per round of 256 tiles
@@ -1045,9 +1246,10 @@ enum TileChoice { TILE_BIG = 0, TILE_MID = 1, TILE_SMALL = 2, TILE_SPLIT = 3, TI
 // are independent, so it is two launches).  Extra-strip plans (plan_rows) cost one more 16-row MFMA tile per workgroup.
 // Examples: U-ViT-L B=64 (M=16448): every shape -> 256x256 in exactly 3 / 1 / 4 / 1 / 1 rounds;
 // U-ViT-S T2I B=64 (M=21376, N=512): 128x128 needs 668 tiles = 1.3 rounds of 512 -> 192x256: 224 tiles, one round.
-TileChoice choose_tile(int M, int N, int* split_rows) {
+TileChoice choose_tile(int M, int N, int* split_rows, TileCosts* costs = nullptr) {
     struct { int M, N; } a{M, N};
     *split_rows = 0;
+    if (costs) for (double& c : costs->c) c = 1e30;
     if (a.N <= 128 || a.M < 192) return TILE_SMALL;   // no half-empty 256-wide tiles
     const int tn = us_cdiv(a.N, 256);
     const long big_tiles = (long)(a.M / 256) * tn;
@@ -1077,6 +1279,7 @@ TileChoice choose_tile(int M, int N, int* split_rows) {
     }
     // the 256x256 form is the measured one on the headline shapes: the others must beat it by a clear margin
     const double best = std::min(std::min(std::min(cost_big * 0.93, cost_mid), std::min(cost_small, cost_split)), cost_tall);
+    if (costs) *costs = TileCosts{{cost_big * 0.93, cost_mid, cost_small, cost_split, cost_tall}};
     if (best == cost_big * 0.93) return TILE_BIG;
     if (best == cost_tall) return TILE_TALL;
     if (best == cost_split) {
@@ -1118,18 +1321,47 @@ inline TileChoice producer_tile(TileChoice tc, int N) {
 std::atomic<int> g_force_tile{-1};        // lab builds: >= 0 overrides the planner's tile form (tools/lab/gemm_ab ... force)
 #endif
 
+// Does the K-split tail beat the form chosen so far?  (Launches of fewer than 32 tiles are the small-launch regime: 64x64 tiles / ring.)
+inline bool sk_wins(int M, int N, int K, TileChoice tc, const TileCosts& cs, SkPlan* p) {
+    if (tc == TILE_TINY || tc == TILE_SK) return false;
+    if (!sk_plan(M, N, K, p) || p->n_dp + p->n_sk < 32) return false;
+#if USPACE_LAB
+    if (const int f = g_force_tile.load(std::memory_order_relaxed); f >= 0) return f == (int)TILE_SK;
+#endif
+    return sk_cost(*p) * 0.93 < cs.c[(int)tc] - 1e-9;
+}
+// The tile form of a launch: choose_tile, then producer_tile for producers of LayerNorm partial sums, refine_small, and the K-split
+// tail where the epilogue has it (sk_ok) and it wins.  A pure function of its arguments: uspace_gemm_part_slots_k / _plan_k answer with it.
+inline TileChoice final_tile(int M, int N, int K, bool producer, bool sk_ok, int* m1, SkPlan* skp) {
+    TileCosts cs;
+    TileChoice tc = choose_tile(M, N, m1, &cs);
+    if (producer) tc = producer_tile(tc, N);
+    tc = refine_small(tc, M, N, K, producer);
+    if (sk_ok && sk_wins(M, N, K, tc, cs, skp)) return TILE_SK;
+    return tc;
+}
+
 template <int FLAGS>
 int dispatch_tile(const GemmArgs& a, hipStream_t s) {
 #if USPACE_FORM4
     if (g_big_form.load(std::memory_order_relaxed) == 2 && us_gemm4_ok(a, FLAGS, true)) return us_gemm4_launch(a, FLAGS, s, true);
 #endif
     int m1 = 0;
-    TileChoice tc = choose_tile(a.M, a.N, &m1);
-    if constexpr ((FLAGS & USPACE_EPI_CEN_OUT) != 0) tc = producer_tile(tc, a.N);
-    tc = refine_small(tc, a.M, a.N, a.K, (FLAGS & USPACE_EPI_CEN_OUT) != 0);
+    constexpr bool PRODUCER = (FLAGS & USPACE_EPI_CEN_OUT) != 0;
+    SkPlan skp;
+    TileChoice tc = final_tile(a.M, a.N, a.K, PRODUCER, sk_flags(FLAGS) && a.n_slab <= 2, &m1, &skp);
 #if USPACE_LAB
-    if (const int f = g_force_tile.load(std::memory_order_relaxed); f >= 0 && f != (int)TILE_SPLIT) tc = (TileChoice)f;
+    if (const int f = g_force_tile.load(std::memory_order_relaxed); f >= 0 && f != (int)TILE_SPLIT && f != (int)TILE_SK) tc = (TileChoice)f;
 #endif
+    if constexpr (sk_flags(FLAGS)) {
+        if (tc == TILE_SK) {
+            if (a.sk_ws && a.sk_cnt && sk_ws_need(skp) <= a.sk_ws_bytes && sk_device_ok()) return launch_sk<FLAGS>(a, s, skp);
+            // no workspace: a producer takes the 256x256 form without the tail -- the partial-sum stride its consumers were told
+            // about (uspace_gemm_part_slots_k) --, any other launch the form it would have had
+            tc = PRODUCER ? TILE_BIG : final_tile(a.M, a.N, a.K, false, false, &m1, &skp);
+        }
+    }
+    if (tc == TILE_SK) return USPACE_ERR_ARG;   // (unreachable: final_tile answers SK only for epilogues that have it)
     if constexpr ((FLAGS & (USPACE_EPI_LN_IN | USPACE_EPI_GELU)) == 0) {
         if (tc == TILE_SMALL && a.split_ws) {
             const int S = split_factor(us_cdiv(a.M, 128) * us_cdiv(a.N, 128), a.K);
@@ -1233,6 +1465,13 @@ extern "C" __attribute__((visibility("default"))) int uspace_lab_gemm_takes_form
 extern "C" __attribute__((visibility("default"))) void uspace_lab_gemm_force_tile(int tc) { g_force_tile.store(tc, std::memory_order_relaxed); }
 #endif
 
+extern "C" int uspace_gemm_set_sk(int mode) {
+    if (mode < -1 || mode > 1) return USPACE_ERR_ARG;
+    g_sk_on.store(mode < 0 ? 1 : mode, std::memory_order_relaxed);
+    return USPACE_OK;
+}
+extern "C" int uspace_gemm_get_sk(void) { return g_sk_on.load(std::memory_order_relaxed); }
+
 extern "C" int uspace_gemm_part_slots_k(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return USPACE_ERR_ARG;
 #if USPACE_LAB
@@ -1244,7 +1483,8 @@ extern "C" int uspace_gemm_part_slots_k(int M, int N, int K) {
     if (g_big_form.load(std::memory_order_relaxed) == 2 && uspace_lab_gemm_takes_form4(M, N, K, K, USPACE_EPI_CEN_OUT | USPACE_EPI_BIAS | USPACE_EPI_OUT_F32)) return N / 256;
 #endif
     int m1 = 0;
-    const TileChoice tc = refine_small(producer_tile(choose_tile(M, N, &m1), N), M, N, K, true);
+    SkPlan skp;
+    const TileChoice tc = final_tile(M, N, K, true, true, &m1, &skp);
     return us_cdiv(N, tc == TILE_TINY ? 64 : (tc == TILE_SMALL || tc == TILE_TALL) ? 128 : 256);
 }
 
@@ -1296,11 +1536,26 @@ extern "C" int uspace_gemm_plan(int M, int N, int* out) {
 extern "C" int uspace_gemm_plan_k(int M, int N, int K, int producer, int* out) {
     if (M <= 0 || N <= 0 || K <= 0 || !out) return USPACE_ERR_ARG;
     int m1 = 0;
-    TileChoice tc = choose_tile(M, N, &m1);
-    if (producer) tc = producer_tile(tc, N);
-    tc = refine_small(tc, M, N, K, producer != 0);
+    SkPlan skp;
+    const TileChoice tc = final_tile(M, N, K, producer != 0, true, &m1, &skp);
+    if (tc == TILE_SK) {     // out[1] = K parts per shared tile, out[7] = whole-tile workgroups in front of them
+        out[0] = (int)tc; out[1] = skp.S; out[2] = out[3] = 256; out[4] = skp.rows.tiles_m; out[5] = skp.tiles_n; out[6] = skp.rows.n_strip; out[7] = skp.n_dp;
+        return USPACE_OK;
+    }
     plan_for(tc, M, N, K, m1, out);
     return USPACE_OK;
+}
+
+/* bytes of uspace_gemm_ext.sk_ws a launch with these sizes needs for the K-split tail (0: the launch has none) */
+extern "C" size_t uspace_gemm_sk_ws_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % BK) return 0;
+    int m1 = 0;
+    SkPlan skp;
+    // (asked without a role: the larger of the two answers)
+    size_t need = 0;
+    for (int producer = 0; producer < 2; ++producer)
+        if (final_tile(M, N, K, producer != 0, true, &m1, &skp) == TILE_SK) need = std::max(need, sk_ws_need(skp));
+    return need;
 }
 
 extern "C" int uspace_gemm_bf16_ext(const uint16_t* A, int lda, const uint16_t* A2, int lda2, int K1,
@@ -1337,9 +1592,14 @@ extern "C" int uspace_gemm_bf16_ext(const uint16_t* A, int lda, const uint16_t* 
     g.ld_cen = 0; g.np_in = 0; g.inv_d = 0.f; g.eps = 0.f;
     g.wide = 0;
     g.nk_split = 0; g.split_stride = 0; g.split_ws = nullptr; g.split_ws_bytes = 0;
+    g.sk_first = 0; g.sk_S = 0; g.sk_ws = nullptr; g.sk_cnt = nullptr; g.sk_ws_bytes = 0;
     if (ext) {
         g.split_ws = (float*)ext->split_ws; g.split_ws_bytes = ext->split_ws_bytes;
         if (g.split_ws && ((uintptr_t)g.split_ws & 15)) return USPACE_ERR_ARG;
+        if (ext->sk_ws && ext->sk_counters) {
+            if (((uintptr_t)ext->sk_ws & 15) || ((uintptr_t)ext->sk_counters & 3)) return USPACE_ERR_ARG;
+            g.sk_ws = (float*)ext->sk_ws; g.sk_ws_bytes = ext->sk_ws_bytes; g.sk_cnt = (unsigned*)ext->sk_counters;
+        }
         g.row_c = ext->row_c; g.out_cen = ext->out_cen; g.ld_cen = ext->ld_cen; g.part_out = ext->part_out;
         g.part_in = ext->part_in; g.np_in = ext->np_in; g.colsum = ext->colsum; g.c_out = ext->c_out;
         g.row_add = ext->row_add; g.col_add = ext->col_add;
@@ -1400,6 +1660,7 @@ extern "C" int uspace_gemm_slabs_bf16(const uint16_t* A, int lda, const uint16_t
     g.ld_cen = 0; g.np_in = 0; g.inv_d = 0.f; g.eps = 0.f;
     if (epi_flags & (USPACE_EPI_CEN_OUT | USPACE_EPI_LN_IN | USPACE_EPI_RANK1)) return USPACE_ERR_ARG;
     g.nk_split = 0; g.split_stride = 0; g.split_ws = nullptr; g.split_ws_bytes = 0;
+    g.sk_first = 0; g.sk_S = 0; g.sk_ws = nullptr; g.sk_cnt = nullptr; g.sk_ws_bytes = 0;
     g.wide = wide_ok(g, epi_flags);
     return dispatch_flags(g, epi_flags, (hipStream_t)stream);
 }

@@ -41,6 +41,14 @@ struct GemmArgs {
     long split_stride;
     float* split_ws;          // host side only: workspace for the K-split form (NULL: never split)
     size_t split_ws_bytes;
+    // K-split tail inside one launch (SK instantiations of the 256x256 form; DESIGN.md "K-split tail"): workgroups [0, sk_first) own
+    // whole tiles, every tile t >= sk_first is shared by sk_S workgroups, each over 1/sk_S of the K tiles; they exchange their fp32
+    // partial sums through sk_ws (write-through stores, one arrival counter per tile in sk_cnt -- zero on entry) and each finishes
+    // the rows it owns.  sk_S = 0: no such tiles.
+    int sk_first, sk_S;
+    float* sk_ws;
+    unsigned* sk_cnt;
+    size_t sk_ws_bytes;       // host side only
 };
 
 constexpr int BK = 64;           // bf16 elements per K step (128 B per LDS row)

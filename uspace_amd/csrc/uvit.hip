@@ -124,8 +124,11 @@ Model build_model(const uspace_uvit_config& c) {
 }
 
 struct Workspace {
-    size_t x, xb, h, qkv, f, skips, ctx_bf, ctx_f32, head, xc, part, cbuf, cskip, splitk, splitk_bytes, total;
+    size_t x, xb, h, qkv, f, skips, ctx_bf, ctx_f32, head, xc, part, cbuf, cskip, splitk, splitk_bytes, sk, sk_bytes, skcnt, skcnt_bytes, total;
 };
+// GEMM launches of one forward that may take the in-launch K-split tail: each gets its own 256 arrival counters, zeroed by ONE
+// memset at the start of the forward (include/uspace_hip.h, uspace_gemm_ext.sk_counters)
+inline int sk_launches(const uspace_uvit_config& c) { return 5 * (c.depth + 1) + c.depth / 2 + 2; }
 
 Workspace plan_workspace(const uspace_uvit_config& c, const Model& m, int B) {
     Workspace w;
@@ -149,6 +152,13 @@ Workspace plan_workspace(const uspace_uvit_config& c, const Model& m, int B) {
     w.splitk_bytes = std::max(std::max(uspace_gemm_split_ws_bytes((int)M, (int)D, (int)D), uspace_gemm_split_ws_bytes((int)M, (int)D, 2 * (int)D)),
                               uspace_gemm_split_ws_bytes((int)M, (int)D, c.mlp_hidden));
     w.splitk = take(w.splitk_bytes);
+    // partial-sum slabs of the in-launch K-split tail (qkv; proj, skip_linear, fc2: N = D) and the launches' arrival counters
+    w.sk_bytes = std::max(std::max(uspace_gemm_sk_ws_bytes((int)M, (int)D, (int)D), uspace_gemm_sk_ws_bytes((int)M, (int)D, 2 * (int)D)),
+                          std::max(uspace_gemm_sk_ws_bytes((int)M, (int)D, c.mlp_hidden), uspace_gemm_sk_ws_bytes((int)M, 3 * (int)D, (int)D)));
+    w.sk_bytes = std::max(w.sk_bytes, uspace_gemm_sk_ws_bytes((int)M, c.mlp_hidden, (int)D));
+    w.sk = take(w.sk_bytes);
+    w.skcnt_bytes = w.sk_bytes ? (size_t)sk_launches(c) * USPACE_GEMM_SK_COUNTERS * 4 : 0;
+    w.skcnt = take(w.skcnt_bytes);
     w.total = off;
     return w;
 }
@@ -264,9 +274,29 @@ extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* bl
     uint16_t* xc = (uint16_t*)(ws + w.xc);
     float* part = (float*)(ws + w.part);
     float* cbuf = (float*)(ws + w.cbuf);
-    uspace_gemm_ext plain{};                          // no LayerNorm folding, only the K-split workspace
+    uspace_gemm_ext plain{};                          // no LayerNorm folding, only the K-split workspaces
     plain.split_ws = w.splitk_bytes ? ws + w.splitk : nullptr;
     plain.split_ws_bytes = w.splitk_bytes;
+    // in-launch K-split tail: one slab workspace (launches of a stream run one after the other), a fresh set of zeroed counters per launch
+    int sk_next = 0;
+    if (w.sk_bytes) {
+        if (hipMemsetAsync(ws + w.skcnt, 0, w.skcnt_bytes, (hipStream_t)stream) != hipSuccess) return USPACE_ERR_LAUNCH;
+        plain.sk_ws = ws + w.sk;
+        plain.sk_ws_bytes = w.sk_bytes;
+    }
+    const int sk_max = sk_launches(c);
+    auto with_sk = [&](uspace_gemm_ext e) {           // e with this launch's counters
+        if (w.sk_bytes && sk_next < sk_max) {
+            e.sk_ws = ws + w.sk;
+            e.sk_ws_bytes = w.sk_bytes;
+            e.sk_counters = ws + w.skcnt + (size_t)(sk_next++) * USPACE_GEMM_SK_COUNTERS * 4;
+        } else {
+            e.sk_ws = nullptr; e.sk_ws_bytes = 0; e.sk_counters = nullptr;
+        }
+        return e;
+    };
+    uspace_gemm_ext sk_tmp;                           // (the call reads it before it returns)
+    auto sk_ptr = [&](const uspace_gemm_ext& e) { sk_tmp = with_sk(e); return (const uspace_gemm_ext*)&sk_tmp; };
     const bool fold = g_ln_fold.load() != 0 && uspace_gemm_part_slots(B * m.L, c.embed_dim) <= 8;   // consumers read <= 8 partial slots per row
     const size_t MD = (size_t)M * D;
 
@@ -326,7 +356,7 @@ extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* bl
                 pskip.row_add = cskip + (size_t)si * M;
                 pskip.col_add = PFx(b.skip_cs2);
                 US_TRY(uspace_gemm_bf16_ext(xb, D, skips + (size_t)si * MD, D, D, PH(b.skip_w), 2 * D, M, D, 2 * D, K_ | C_ | B_ | F_, PF(b.skip_b),
-                                            nullptr, 0, x, D, nullptr, 0, &pskip, stream));
+                                            nullptr, 0, x, D, nullptr, 0, sk_ptr(pskip), stream));
                 np = slots_skip;
                 cen_in = xc;
                 c_in = cbuf;
@@ -339,7 +369,7 @@ extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* bl
             const float* ks = io->key_scale ? io->key_scale + (size_t)i * B * L : nullptr;
             US_TRY(uspace_attention_bf16(qkv, ks, h, B, L, H, stream));
             US_TRY(uspace_gemm_bf16_ext(h, D, nullptr, 0, D, PH(b.projw), D, M, D, D, C_ | B_ | R_ | F_, PF(b.projb), x, D, x, D,
-                                        nullptr, 0, &prod, stream));
+                                        nullptr, 0, sk_ptr(prod), stream));
             np = slots_proj;
             cons.row_c = cbuf;
             cons.np_in = np;
@@ -353,7 +383,7 @@ extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* bl
                 pin.row_c = cskip + (size_t)i * M;
                 pin.out_cen = skips + (size_t)i * MD;
                 US_TRY(uspace_gemm_bf16_ext(f, Hd, nullptr, 0, Hd, PH(b.fc2w), Hd, M, D, Hd, C_ | B_ | R_ | F_, PF(b.fc2b), x, D,
-                                            x, D, nullptr, 0, &pin, stream));
+                                            x, D, nullptr, 0, sk_ptr(pin), stream));
                 np = slots_fc2;
                 cen_in = skips + (size_t)i * MD;
                 c_in = cskip + (size_t)i * M;
@@ -361,7 +391,7 @@ extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* bl
                 // mid / out blocks: the next consumer is skip_linear (raw bf16 xb) or the head (its own norm)
                 uint16_t* copy = is_last ? nullptr : xb;
                 US_TRY(uspace_gemm_bf16_ext(f, Hd, nullptr, 0, Hd, PH(b.fc2w), Hd, M, D, Hd, copy ? (B_ | R_ | F_ | H_) : (B_ | R_ | F_),
-                                            PF(b.fc2b), x, D, x, D, copy, D, &plain, stream));
+                                            PF(b.fc2b), x, D, x, D, copy, D, sk_ptr(plain), stream));
             }
             if (i == half) {
                 if (io->mid_tap) {
@@ -380,7 +410,7 @@ extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* bl
             // x = skip_linear(cat([x, skip]))  -- two K slabs, skips popped LIFO (libs/uvit.py:159,340)
             const uint16_t* skip = skips + (size_t)(m.nblocks - 1 - i) * MD;
             US_TRY(uspace_gemm_bf16_ext(xb, D, skip, D, D, PH(b.skip_w), 2 * D, M, D, 2 * D, B_ | F_, PF(b.skip_b),
-                                        nullptr, 0, x, D, nullptr, 0, &plain, stream));
+                                        nullptr, 0, x, D, nullptr, 0, sk_ptr(plain), stream));
         }
         // x += proj(attn(norm1(x)))
         US_TRY(uspace_layernorm_f32_bf16(x, PF(b.n1w), PF(b.n1b), h, M, D, 1e-5f, stream));
@@ -389,7 +419,7 @@ extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* bl
         const float* ks = io->key_scale ? io->key_scale + (size_t)i * B * L : nullptr;
         US_TRY(uspace_attention_bf16(qkv, ks, h, B, L, H, stream));
         US_TRY(uspace_gemm_bf16_ext(h, D, nullptr, 0, D, PH(b.projw), D, M, D, D, B_ | R_ | F_, PF(b.projb), x, D, x, D,
-                                    nullptr, 0, &plain, stream));
+                                    nullptr, 0, sk_ptr(plain), stream));
         // x += fc2(gelu(fc1(norm2(x))))
         US_TRY(uspace_layernorm_f32_bf16(x, PF(b.n2w), PF(b.n2b), h, M, D, 1e-5f, stream));
         US_TRY(uspace_gemm_bf16(h, D, nullptr, 0, D, PH(b.fc1w), D, M, Hd, D, B_ | G_ | H_, PF(b.fc1b), nullptr, 0,
@@ -397,7 +427,7 @@ extern "C" int uspace_uvit_forward(const uspace_uvit_config* cfg, const void* bl
         // bf16 copy of the block output: the skip (in-blocks) or the next skip_linear's first K slab
         uint16_t* copy = is_in ? skips + (size_t)i * MD : (is_last ? nullptr : xb);
         US_TRY(uspace_gemm_bf16_ext(f, Hd, nullptr, 0, Hd, PH(b.fc2w), Hd, M, D, Hd, copy ? (B_ | R_ | F_ | H_) : (B_ | R_ | F_),
-                                    PF(b.fc2b), x, D, x, D, copy, D, &plain, stream));
+                                    PF(b.fc2b), x, D, x, D, copy, D, sk_ptr(plain), stream));
         if (i == half) {
             if (io->mid_tap) {
                 if (hipMemcpyAsync(io->mid_tap, x, MD * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)

@@ -30,6 +30,7 @@ class UViT(UViTBase):
                          mlp_time_embed=mlp_time_embed, conv=conv, skip=skip,
                          n_extra=1 if has_label else 0, clip_dim=0, time_first=0)
         self.latent_1d = use_latent1d
+        self.use_checkpoint = bool(use_checkpoint)    # no effect on sampling (no backward here); kept for compat/_training.py's twin
 
         def extras():
             if has_label:

@@ -30,6 +30,7 @@ class UViT(UViTBase):
                          depth=depth, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
                          mlp_time_embed=mlp_time_embed, conv=conv, skip=skip,
                          n_extra=num_clip_token, clip_dim=clip_dim, time_first=1)
+        self.use_checkpoint = bool(use_checkpoint)    # no effect on sampling (no backward here); kept for compat/_training.py's twin
 
         def extras():
             self.context_embed = ParamGroup()
