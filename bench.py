@@ -222,7 +222,7 @@ class Runtime:
 
     def init_group(self, rank, world):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(self.backend, rank=rank, world_size=world, device_id=self.device)
+        dist.init_process_group(self.backend, rank=rank, world_size=world, device_id=self.device, timeout=group_timeout())
 
     def synchronize(self):
         torch.cuda.synchronize()
@@ -236,6 +236,14 @@ class Runtime:
 
 
 RUNTIME = Runtime
+
+
+def group_timeout():
+    """Bound on every collective of the run (default 10 minutes; USPACE_BENCH_PG_TIMEOUT_S): a rank that dies mid-solve must not leave the
+    others waiting in the gather for ever.  (Under `python -m torch.distributed.run` the agent also ends the other ranks as soon as one exits
+    with an error; this bound is for every other launch form and for a rank that hangs instead of dying.)"""
+    import datetime
+    return datetime.timedelta(seconds=float(os.environ.get("USPACE_BENCH_PG_TIMEOUT_S", "600")))
 
 
 def relaunch_argv(gpus, port, argv):
@@ -557,4 +565,9 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException as ex:   # name the rank: with N ranks the first error is the one that matters, the others fail in the gather after it
+        if not isinstance(ex, SystemExit) or ex.code not in (0, None):
+            print(f"bench.py: rank {os.environ.get('RANK', '0')} of {os.environ.get('WORLD_SIZE', '1')} failed: {type(ex).__name__}: {ex}", file=sys.stderr, flush=True)
+        raise

@@ -165,3 +165,123 @@ def test_group_controlled_adaptive_solve_follows_the_single_process_step_sequenc
         # per-rank control is a different (still valid) discretisation: some rank takes other steps
         assert any(r["local_differs"] for r in res), res
         assert all(r["err_local"] < 1e-3 for r in res)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Eight ranks (the node the driver scales to; VERDICT r5 task 5): the shard sizes of BASELINE configs 4 and 5 (512 and 256 rows
+# over 8 GPUs), an uneven job, the group-controlled adaptive solve, and a rank that fails mid-solve.
+# ------------------------------------------------------------------------------------------------------------------
+def _worker8(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from uspace_amd.sampling import gather_batch, shard_bounds, sharded_sample
+    ok = True
+    for n_total, want in ((512, [64] * 8), (256, [32] * 8), (250, [32, 32, 31, 31, 31, 31, 31, 31]), (5, [1, 1, 1, 1, 1, 0, 0, 0])):
+        sizes = [shard_bounds(n_total, world, r)[1] - shard_bounds(n_total, world, r)[0] for r in range(world)]
+        ok = ok and sizes == want
+        g = torch.Generator().manual_seed(7)
+        z = torch.randn(n_total, 4, 4, 4, generator=g)
+        cond = torch.arange(n_total, dtype=torch.float32)
+        seen = []
+
+        def solve(z_local, c_local):
+            seen.append(z_local.shape[0])
+            return z_local * 2.0 + c_local.view(-1, 1, 1, 1) + 1000.0 * 0      # rows keep their global identity through cond
+        out = sharded_sample(solve, z, cond)
+        lo, hi = shard_bounds(n_total, world, rank)
+        ok = ok and seen == [hi - lo] and out.shape[0] == n_total and torch.equal(out, z * 2.0 + cond.view(-1, 1, 1, 1))
+        ok = ok and torch.equal(gather_batch(z[lo:hi], n_total), z)             # an empty shard gathers too
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(target, world, extra=(), timeout=240):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port) + tuple(extra) + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    return procs, q
+
+
+def test_eight_rank_shard_and_gather_at_the_baseline_shard_sizes():
+    procs, q = _run(_worker8, 8)
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == {r: True for r in range(8)}
+
+
+def test_eight_rank_group_controlled_adaptive_solve():
+    """CNF.norm_group on 8 ranks: 250 trajectories (31 / 32 per rank), the stiff ones on the last ranks -- every rank follows the
+    step sequence of the unsharded solve; per-rank control takes other steps on some rank."""
+    procs, q = _run(_adaptive_worker, 8, extra=(250,))
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in res:
+        assert r["same_steps"] and r["nfe"][0] == r["nfe"][1] and r["acc"][0] == r["acc"][1] and r["rej"][0] == r["rej"][1], r
+        assert r["err"] < 1e-6, r
+    assert any(r["local_differs"] for r in res) and len({r["nfe"][2] for r in res}) > 1       # per-rank control: different NFE per rank
+    assert all(r["err_local"] < 1e-3 for r in res)
+
+
+def _failing_worker(rank, world, port, bad_rank, q):
+    import datetime
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=30))
+    from uspace_amd.sampling import sharded_sample
+    z = torch.randn(256, 4, 4, 4, generator=torch.Generator().manual_seed(3))
+    calls = [0]
+
+    def solve(z_local):
+        for step in range(5):                                   # a rank dies in the middle of its solve, before the gather
+            calls[0] += 1
+            if rank == bad_rank and step == 2:
+                raise ValueError(f"synthetic failure on rank {rank} at step {step}")
+            z_local = z_local * 0.9
+        return z_local
+    import time
+    t0 = time.time()
+    def leave(msg, code):                                       # (flush the queue's feeder thread: os._exit would drop the message)
+        q.put(msg)
+        q.close()
+        q.join_thread()
+        os._exit(code)                                          # the process ends as a crashed rank does: no barrier, no destroy
+    try:
+        sharded_sample(solve, z)
+        leave((rank, "returned", time.time() - t0, ""), 0)
+    except ValueError as ex:
+        leave((rank, "own", time.time() - t0, str(ex)), 3)
+    except RuntimeError as ex:
+        leave((rank, "peer", time.time() - t0, str(ex)), 4)
+
+
+def test_a_rank_that_fails_mid_solve_does_not_leave_the_others_in_the_gather():
+    """One of 8 ranks raises inside its solve.  The others are in the all_gather of the final latents by then: each of them must come
+    back with an error that names the collective and tells where to look -- within the group's timeout (30 s here; gloo notices the
+    closed connections at once), not hang.  What bench.py adds on top: the same bound on its process group (USPACE_BENCH_PG_TIMEOUT_S,
+    default 600 s), a line on stderr naming the failing rank, and under torch.distributed.run the agent ends the other ranks itself."""
+    procs, q = _run(_failing_worker, 8, extra=(5,))
+    res = {}
+    for _ in procs:
+        r = q.get(timeout=120)
+        res[r[0]] = r
+    for p in procs:
+        p.join(60)
+        assert p.exitcode is not None
+    assert res[5][1] == "own" and "synthetic failure on rank 5" in res[5][3]
+    for r in range(8):
+        if r == 5:
+            continue
+        kind, dt, msg = res[r][1], res[r][2], res[r][3]
+        assert kind == "peer", res[r]
+        assert "gather_batch" in msg and "a peer rank has failed" in msg and f"rank {r} of 8" in msg, msg
+        assert dt < 60, res[r]
+    assert [p.exitcode for p in procs] == [4, 4, 4, 4, 4, 3, 4, 4]

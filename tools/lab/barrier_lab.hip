@@ -39,7 +39,8 @@ __global__ __launch_bounds__(256) void flat_barriers(unsigned* cnt, int n, float
     const unsigned nb = gridDim.x;
     for (int k = 0; k < n; ++k) {
         if (payload) {   // 16 KiB per workgroup: 256 threads x 4 x float4
-            float4* mine = (float4*)(buf + (size_t)blockIdx.x * 4096);
+            // (two buffers by barrier parity: a workgroup past barrier k writes phase k + 1 while a slower one still reads phase k)
+            float4* mine = (float4*)(buf + ((size_t)(k & 1) * nb + blockIdx.x) * 4096);
             for (int i = 0; i < 4; ++i) mine[threadIdx.x + 256 * i] = make_float4(k, blockIdx.x, i, threadIdx.x);
         }
         __syncthreads();
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void flat_barriers(unsigned* cnt, int n, float
         }
         __syncthreads();
         if (payload) {
-            const float4* other = (const float4*)(buf + (size_t)((blockIdx.x + 37) % nb) * 4096);
+            const float4* other = (const float4*)(buf + ((size_t)(k & 1) * nb + (blockIdx.x + 37) % nb) * 4096);
             float4 s = make_float4(0, 0, 0, 0);
             for (int i = 0; i < 4; ++i) {
                 const float4 v = other[threadIdx.x + 256 * i];
@@ -86,7 +87,7 @@ int main(int argc, char** argv) {
     unsigned* cnt;
     float* buf;
     HCHECK(hipMalloc(&cnt, 4096));
-    HCHECK(hipMalloc(&buf, (size_t)256 * 4096 * 4));
+    HCHECK(hipMalloc(&buf, (size_t)2 * 256 * 4096 * 4));
     hipStream_t s;
     HCHECK(hipStreamCreate(&s));
     hipEvent_t e0, e1;

@@ -34,7 +34,13 @@ def gather_batch(local, n_total, group=None):
     if local.shape[0] < max_rows:
         pad = torch.cat([local, local.new_zeros((max_rows - local.shape[0],) + tuple(local.shape[1:]))], dim=0)
     bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad.contiguous(), group=group)
+    try:
+        dist.all_gather(bufs, pad.contiguous(), group=group)
+    except Exception as ex:       # a peer that died mid-solve (or the group's timeout): say which collective and who noticed
+        raise RuntimeError(
+            f"uspace_amd.sampling.gather_batch: the all_gather of the final latents failed on rank {dist.get_rank(group)} of {world} "
+            f"({n_total} rows in all) -- a peer rank has failed or did not arrive within the process group's timeout; its own error "
+            f"is in that rank's output.  [{type(ex).__name__}: {str(ex)[:200]}]") from ex
     return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)
 
 
