@@ -76,11 +76,81 @@ def test_config2_batch_slices_are_independent_and_deterministic(net_L_u):
     assert torch.equal(a, b) and bool(torch.isfinite(a).all())
     sub, _ = net_L_u(z[24:32].contiguous(), _t(0.35, 8), None, edit_loc=None)
     r = rel_l2(sub.cpu().numpy(), a[24:32].cpu().numpy())
-    # different tile shapes (128x128 vs 256x256+strip) change the fp32 summation grouping of the GEMMs and of the folded
-    # LayerNorm statistics; through 21 blocks of bf16 operands that moves the result by about the distance to the fp32
-    # reference itself (5e-3 for this model, tests/test_gpu_forward.py::test_big_shapes_match_reference_golden)
+    # a SMOKE line only: different tile shapes change the fp32 summation grouping of the folded LayerNorm statistics (and fc2's K
+    # parts); through 21 blocks of bf16 operands that moves the result by about the distance to the fp32 reference itself (5e-3,
+    # tests/test_gpu_forward.py::test_big_shapes_match_reference_golden), so this bound cannot see a small tile-plan bug -- the
+    # launch-by-launch comparison below (test_every_launch_of_a_block_is_the_same_at_every_batch_size) is the check that can
     assert r < 6e-3, r
     assert float(a.std()) > 1e-3
+
+
+@pytest.mark.parametrize("sub", [(24, 32), (0, 32), (16, 64)])
+def test_every_launch_of_a_block_is_the_same_at_every_batch_size(sub):
+    """The end-to-end slice check above cannot see an error below one forward's bf16 noise.  This one compares
+    launch by launch: each GEMM of a U-ViT-L block on 64 x 257 rows (256x256 tiles + strips) against the same rows [lo, hi) x 257
+    launched on their own -- 8, 32 and 48 samples: 64x64 / 128x128, 256x128, 192x256 tiles, other row plans, the in-launch K-split
+    tail for fc2.  Every tile form walks K in the same order with the same MFMA, so outputs are BIT-EQUAL whenever no form splits K
+    (qkv, fc1 + GELU, skip_linear over two K slabs, proj with its residual: the residual is the accumulator's initial value in every
+    form); fc2 at the smaller row counts runs in K parts (p0 + p1 + ...): equal to fp32 summation order."""
+    import ctypes
+    from uspace_amd import _hip
+    lo, hi = sub[0] * 257, sub[1] * 257
+    M, D = 64 * 257, 1024
+    g = torch.Generator().manual_seed(21)
+    x_bf = (torch.randn(M, D, generator=g) * 1.0).to(torch.bfloat16).cuda()
+    f_bf = (torch.randn(M, 4 * D, generator=g) * 0.7).to(torch.bfloat16).cuda()
+    s_bf = (torch.randn(M, D, generator=g) * 1.0).to(torch.bfloat16).cuda()
+    resid = torch.randn(M, D, generator=g).cuda()
+    W = {k: (torch.randn(n, kk, generator=g) * 0.03).to(torch.bfloat16).cuda()
+         for k, (n, kk) in dict(qkv=(3 * D, D), proj=(D, D), fc1=(4 * D, D), fc2=(D, 4 * D), skip=(D, 2 * D)).items()}
+    bias = {k: torch.randn(w.shape[0], generator=g).cuda() for k, w in W.items()}
+    plan = (ctypes.c_int * 8)()
+
+    def form(m, n, k):
+        _hip.check(_hip.lib().uspace_gemm_plan_k(m, n, k, 0, plan), "plan")
+        return plan[0]
+
+    def run(name, rows):
+        a_x, a_f, a_s, r = x_bf[rows], f_bf[rows], s_bf[rows], resid[rows].clone()
+        m = a_x.shape[0]
+        sk = None
+        need = _hip.lib().uspace_gemm_sk_ws_bytes(m, D, 4 * D)
+        if name == "fc2" and need:
+            sk = torch.empty(need, dtype=torch.uint8, device="cuda")
+        if name == "qkv":
+            o = torch.empty(m, 3 * D, dtype=torch.bfloat16, device="cuda")
+            _hip.gemm(a_x, W["qkv"], out_bf16=o)
+            return o
+        if name == "fc1":
+            o = torch.empty(m, 4 * D, dtype=torch.bfloat16, device="cuda")
+            _hip.gemm(a_x, W["fc1"], bias=bias["fc1"], gelu=True, out_bf16=o)
+            return o
+        if name == "skip":
+            o = torch.empty(m, D, device="cuda")
+            ob = torch.empty(m, D, dtype=torch.bfloat16, device="cuda")
+            _hip.gemm(a_x, W["skip"], A2=a_s, bias=bias["skip"], out_f32=o, out_bf16=ob)
+            return o
+        if name == "proj":
+            _hip.gemm(a_x, W["proj"], bias=bias["proj"], resid=r, out_f32=r)
+            return r
+        ob = torch.empty(m, D, dtype=torch.bfloat16, device="cuda")
+        _hip.gemm(a_f, W["fc2"], bias=bias["fc2"], resid=r, out_f32=r, out_bf16=ob, sk_ws=sk)
+        return r
+
+    all_rows, part = slice(0, M), slice(lo, hi)
+    forms = {}
+    for name, (n, k) in dict(qkv=(3 * D, D), fc1=(4 * D, D), skip=(D, 2 * D), proj=(D, D), fc2=(D, 4 * D)).items():
+        big = run(name, all_rows)[lo:hi]
+        small = run(name, part)
+        forms[name] = (form(M, n, k), form(hi - lo, n, k))
+        split_k = name == "fc2" and 6 in forms[name]
+        if split_k:
+            d = (big.float() - small.float()).abs().max().item()
+            assert d <= 2e-5 * big.float().abs().max().item(), (name, forms[name], d)
+        else:
+            assert torch.equal(big, small), (name, forms[name], (big.float() - small.float()).abs().max().item())
+    # the point of the comparison: the sub-batch really ran on other tile forms / row plans than the batch of 64
+    assert any(a != b for a, b in forms.values()) or sub == (16, 64), forms
 
 
 def test_config2_solver_roundtrip_and_shard_equivalence(net_L_u):
