@@ -153,6 +153,49 @@ def test_every_launch_of_a_block_is_the_same_at_every_batch_size(sub):
     assert any(a != b for a, b in forms.values()) or sub == (16, 64), forms
 
 
+@pytest.mark.parametrize("B", [32, 16])
+def test_k_split_tail_inside_the_model_is_reproducible_and_matches_the_switch_off(net_L_u, B):
+    """U-ViT-L at 32 (config 5's share) and 16 per GPU: every fc2 of the forward shares its tiles between 2 / 4 workgroups that
+    exchange partial sums inside the launch (write-through stores + one arrival counter per tile, counters of all launches zeroed by one
+    memset per forward).  (a) 24 forwards in a row, other inputs in between (the exchange workspace is reused by all 21 fc2 launches of
+    every forward, under the load of the forward itself): bit-identical -- a stale slab line or a counter left over would show;
+    (b) hipGraph replay (the memset and the per-launch counter slices are captured) == eager; (c) with the switch off
+    (uspace_gemm_set_sk(0): the round-5 tile forms) the same numbers to the bf16 noise floor of a forward."""
+    from uspace_amd import _hip
+    L = _hip.lib()
+    import ctypes
+    plan = (ctypes.c_int * 8)()
+    _hip.check(L.uspace_gemm_plan_k(B * 257, 1024, 4096, 1, plan), "plan")
+    assert plan[0] == 6 and plan[1] == (2 if B == 32 else 4), list(plan)
+    z, z2 = _z(B), _z(B, seed=8)
+    first, _ = net_L_u(z, _t(0.35, B), None, edit_loc=None)
+    first = first.clone()
+    for rep in range(24):
+        net_L_u(z2, _t(0.1 + 0.03 * rep, B), None, edit_loc=None)
+        again, _ = net_L_u(z, _t(0.35, B), None, edit_loc=None)
+        assert torch.equal(again, first), rep
+    was = net_L_u.use_graph
+    try:
+        net_L_u.use_graph = True
+        for _ in range(3):
+            g, _aux = net_L_u(z, _t(0.35, B), None, edit_loc=None)
+            assert torch.equal(g, first)
+    finally:
+        net_L_u.use_graph = was
+    try:
+        _hip.check(L.uspace_gemm_set_sk(0), "set_sk")
+        net_L_u._workspace.clear()                        # sized for the other plan
+        _hip.check(L.uspace_gemm_plan_k(B * 257, 1024, 4096, 1, plan), "plan")
+        assert plan[0] != 6
+        off, _ = net_L_u(z, _t(0.35, B), None, edit_loc=None)
+    finally:
+        L.uspace_gemm_set_sk(-1)
+        net_L_u._workspace.clear()
+    assert L.uspace_gemm_get_sk() == 1
+    r = rel_l2(off.cpu().numpy(), first.cpu().numpy())
+    assert 0 < r < 6e-3, r
+
+
 def test_config2_solver_roundtrip_and_shard_equivalence(net_L_u):
     """Euler/RK4 fixed steps at batch 64: encode then decode returns the input; solving two half batches
     (what two ranks would do) reproduces the full-batch solve."""

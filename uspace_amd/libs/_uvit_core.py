@@ -76,7 +76,7 @@ class UViTBase(nn.Module):
         # copies into / out of the graph's static buffers (U-ViT-S at batch 4: 15.14 ms per 20-step solve against 14.84 eager).
         # ``USPACE_UVIT_GRAPH=1`` or ``net.use_graph = True`` turn it on (a host that cannot keep ahead of the GPU).
         self.use_graph = os.environ.get("USPACE_UVIT_GRAPH", "0") == "1"
-        self._graphs = {}            # (B, device, blob ptr, has ctx, LN-fold mode) -> _GraphEntry (at most _MAX_GRAPHS)
+        self._graphs = {}            # (B, device, blob ptr, has ctx, LN-fold mode, K-split-tail switch) -> _GraphEntry (at most _MAX_GRAPHS)
 
     # ------------------------------------------------------------------ parameter tree
     def _build_tree(self, extra_builder):
@@ -221,8 +221,10 @@ class UViTBase(nn.Module):
         with plain B solves (tools/utils_vis.py:189-198), and one slot would reallocate hundreds of MB at every switch."""
         key = (B, str(device))
         ws = self._workspace.pop(key, None)
-        if ws is None:
-            nbytes = _hip.lib().uspace_uvit_workspace_bytes(ctypes.byref(self._cfg), B)
+        # (asked every time: a host-side query; the size depends on the library's process-wide switches -- uspace_gemm_set_sk --, and a
+        # workspace sized under another setting must not be handed on)
+        nbytes = _hip.lib().uspace_uvit_workspace_bytes(ctypes.byref(self._cfg), B)
+        if ws is None or ws.numel() < nbytes:
             while len(self._workspace) >= self._MAX_WORKSPACES:
                 self._workspace.pop(next(iter(self._workspace)))          # dicts keep insertion order: the oldest use
             ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -234,7 +236,7 @@ class UViTBase(nn.Module):
 
     def _graph_entry(self, B, dev, blob, context):
         # a captured graph replays the launch sequence of the LayerNorm mode it was captured in
-        key = (B, str(dev), blob.data_ptr(), context is not None, _hip.lib().uspace_uvit_get_ln_fold())
+        key = (B, str(dev), blob.data_ptr(), context is not None, _hip.lib().uspace_uvit_get_ln_fold(), _hip.lib().uspace_gemm_get_sk())
         ent = self._graphs.get(key)
         if ent is not None:
             return ent
