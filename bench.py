@@ -454,11 +454,14 @@ def main():
                     extra[f"{tag}_steps_rejected"] = [int(r[3]) for r in rows] if world > 1 else int(rows[0][3])
                 finally:
                     cnf.norm_group = prev
-            adaptive_reading("dopri5_adaptive", None)
-            extra["dopri5_adaptive_note"] = ("reference default: dopri5, rtol = atol = 1e-5 (flow_matching.py:78-84), NFE data-dependent; per-rank step control; "
-                                             "one warm-up solve, then one timed solve (max over ranks)")
-            if world > 1:
-                adaptive_reading("dopri5_adaptive_norm_group", True)
+            try:                                   # auxiliary figures, never fatal (an error here is the same on every rank: host-side code)
+                adaptive_reading("dopri5_adaptive", None)
+                extra["dopri5_adaptive_note"] = ("reference default: dopri5, rtol = atol = 1e-5 (flow_matching.py:78-84), NFE data-dependent; per-rank step control; "
+                                                 "one warm-up solve, then one timed solve (max over ranks)")
+                if world > 1:
+                    adaptive_reading("dopri5_adaptive_norm_group", True)
+            except Exception as ex:
+                extra["dopri5_adaptive_error"] = repr(ex)
             if world == 1 and dev.type == "cuda":
                 # latents -> 256^2 images through the VAE decoder; outside the timed region and
                 # outside `value`, reported so the latent->latent figure can be read as an end-to-end one

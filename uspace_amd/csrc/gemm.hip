@@ -711,7 +711,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
     // ---- SK: the K parts of a shared tile exchange their partial sums.  Part p finishes the row sub-tiles [own_lo, own_hi) of every wave
     //      (and part 0 the strip): it publishes the others' rows of its accumulators -- 16-byte write-through (sc1) stores in register
     //      order, 1 KiB per wave and sub-tile --, drains, arrives at the tile's counter, waits for all sk_S arrivals (relaxed polls by one
-    //      lane, then ONE agent-scope acquire) and adds the partners' values for its own rows in part order: p0 + p1 + ..., whoever
+    //      lane, then ONE agent-scope acquire) and adds the partners' values to its own for its rows, partners in part order, whoever
     //      arrives when -- bit-identical run to run.  All parts of all shared tiles are resident together (<= 256 workgroups of one per
     //      CU, the whole-tile workgroups in front of them never wait), so the wait ends; a poll count that cannot be reached traps.
     int own_lo = 0, own_hi = TM;
@@ -756,34 +756,39 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __syncthreads();
-            // (one row sub-tile at a time: requesting the partners' values of several sub-tiles before the first add -- 16 to 24 loads of 16
-            // bytes per lane -- was tried and spills next to the 128 accumulator registers)
+            // The partners' values of this part's rows come back through LDS (free after the K loop): each wave requests ALL of its pieces
+            // of one partner with LDS-DMA -- up to 16 x 1 KiB in flight, no registers -- into its own 16 KiB, waits once, and adds them
+            // from there (lane-linear image: a lane reads back the 16 bytes it asked for).  Plain loads into registers were one dependent
+            // trip to the memory side per row sub-tile (4 loads in flight per lane; 16-24 at once spill next to the 128 accumulator
+            // registers) and made the exchange latency-bound.  Summation order: own + partners in part order -- a fixed function of
+            // (tile, rows), bit-identical run to run.
+            constexpr int MAXOWN = (TM + 1) / 2;                      // S >= 2 parts: a part owns at most ceil(TM / 2) sub-tiles
+            static_assert(WM * WN * MAXOWN * TN * 1024 <= NST * STAGE_BYTES, "the waves' landing zones fit the stage buffers");
+            char* const zone = smem + wave * (MAXOWN * TN * 1024);
+            for (int q = 0; q < 3; ++q) {
+                const int t = q + (q >= sk_split ? 1 : 0);          // partner q: the parts other than this one, in part order
+                if (t >= S) break;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(slabs + (size_t)t * SLAB_BYTES), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                if (i < own_lo || i >= own_hi) continue;
-                f32x4 pv[4][TN];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (t < S && t != sk_split) {
+                for (int o = 0; o < MAXOWN; ++o) {
+                    const int i = own_lo + o;
+                    if (i < own_hi) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            pv[t][j] = *(const f32x4*)(slabs + (size_t)t * SLAB_BYTES + lane_off + (uint32_t)(i * TN + j) * 1024u);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) pv[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (US_LDS void*)(zone + (o * TN + j) * 1024), 16, lane_off + (uint32_t)(i * TN + j) * 1024u, 0, 0, 0);
                     }
                 }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces have landed (nobody else touches its zone)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    // p0 + p1 + ... in part order, this part's own accumulator at its place
-                    f32x4 v = sk_split == 0 ? acc[i][j] : pv[0][j];
+                for (int i = 0; i < TM; ++i) {
 #pragma unroll
-                    for (int t = 1; t < 4; ++t) {
-                        const f32x4 w = v + (t == sk_split ? acc[i][j] : pv[t][j]);
-                        v = t < S ? w : v;
+                    for (int o = 0; o < MAXOWN; ++o) {
+                        if (i - own_lo != o || i >= own_hi) continue;   // (constant indices on both sides: a run-time accumulator index would go to scratch)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] += *(const f32x4*)(zone + (o * TN + j) * 1024 + lane * 16);
                     }
-                    acc[i][j] = v;
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and have been read before the next partner's overwrite them
             }
             if constexpr (XTRA) {
                 if (has_x && sk_split == 0) {
@@ -800,6 +805,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && (NST == 2 || BM == 6
         }
     }
     const bool own_x = !SK || sk_split == 0;      // the strip rows belong to K part 0
+    if constexpr (SK) __syncthreads();            // (the epilogue's partial-sum buffer reuses the memory the exchange landed in)
 
     // ---- epilogue: lane holds, for sub-tile (i,j), row m = ..+fr and columns n = ..+4*fq+{0,1,2,3}
     if constexpr (!EARLY_EPI) load_epi_consts();
@@ -1032,8 +1038,12 @@ struct SkPlan {
 // out and back in: 67 MB for 128 tiles, beside the 100-160 MB such a launch moves anyway) and costs 14-25 us whatever K is; what it buys
 // is 1 - 1/S of the K loop.  It pays for K = 4096 (64 K tiles: fc2 of U-ViT-L -- 0.84 at 16 x 257 rows, 0.96-0.99 at 32 x 257 / 64 x 334 /
 // 96 x 257) and loses 4-40 % for K <= 2048 (proj, skip_linear, qkv), so the plan exists for K loops of 64 tiles or more only.
+#if USPACE_LAB && defined(USPACE_SK_MIN_NK)      // lab builds: admit shorter K loops (tools/lab/build_variant.sh ... "-DUSPACE_SK_MIN_NK=16 -DUSPACE_SK_MIN_KT=4")
+constexpr int SK_MIN_NK = USPACE_SK_MIN_NK, SK_MIN_KT = USPACE_SK_MIN_KT;
+#else
 constexpr int SK_MIN_NK = 64;           // K tiles of the whole K loop at the least
 constexpr int SK_MIN_KT = 16;           // ... and per part
+#endif
 constexpr double SK_FIXED = 0.10;       // the exchange, in units of a round of 256x256 tiles of such a K loop (14 of 141 us)
 std::atomic<int> g_sk_on{1};            // process-wide switch (include/uspace_hip.h: uspace_gemm_set_sk)
 inline bool sk_plan(int M, int N, int K, SkPlan* out) {
