@@ -745,7 +745,8 @@ def _sk_ext(hip, ext, M, N, K):
     (32 * 257, 1024, 4096, 2, 0),     # config 5 fc2: 128 tiles + 2 strips, every tile in 2 K parts
     (16 * 257, 1024, 4096, 4, 0),     # 64 tiles in 4 K parts (16 K tiles each)
     (96 * 257, 1024, 4096, 2, 256),   # 384 tiles = one round + 128 tiles in 2 parts
-    (30 * 256 + 500, 1024, 4096, 2, 0),   # 31 tile rows of which the last holds 500 - 256 rows (more than one strip per tile row can take): no strips
+    (30 * 256 + 500, 1024, 4096, 2, 0),   # 31 tile rows + 16 strips (244 rows left), 124 tiles in 2 parts
+    (10 * 256 + 200, 1024, 4096, 4, 0),   # 200 rows left are more than 10 tile rows can take as strips: an 11th, partly filled tile row, no strips; 44 tiles in 4 parts
     (20 * 257 + 200, 1024, 4096, 3, 0),   # 20 tile rows + 14 strips: 80 tiles in 3 parts
     (24 * 257, 1024, 4096, 0, 0),         # 96 tiles: two parts would leave a quarter of the CUs idle -- no tail
     (64 * 334, 1024, 1024, 0, 0),     # K below 64 tiles: no tail (the exchange costs more than the K loop it saves, profiles/r06_sk_tail.md)

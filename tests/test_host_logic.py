@@ -628,6 +628,49 @@ def test_gemm_plans_on_random_shapes():
     check()
 
 
+def test_gemm_k_split_tail_plans_and_switch():
+    """The in-launch K-split tail (round 6) as the host sees it: which BASELINE launches have one (fc2 of U-ViT-L -- K = 4096 -- at the row
+    counts whose 256x256 tiles do not fill whole rounds; never the headline, never K <= 2048, never U-ViT-S), its workspace size, the
+    partial-sum slots a producer then writes, and the process-wide switch (every query answers for the current setting)."""
+    from uspace_amd import _hip
+    L = _hip.lib()
+    out = (ctypes.c_int * 8)()
+
+    def plan(M, N, K, prod=1):
+        assert L.uspace_gemm_plan_k(M, N, K, prod, out) == 0
+        return list(out)
+    slab, slab_x = 256 * 1024, 272 * 1024
+    try:
+        assert L.uspace_gemm_get_sk() == 1
+        # config 3 (64 x 334 rows): one whole round + 76 tiles in 3 K parts, 8 strips; config 5 (32 x 257): 128 tiles x 2, 2 strips; 16 per GPU: x 4
+        assert plan(64 * 334, 1024, 4096)[:2] == [6, 3] and plan(64 * 334, 1024, 4096)[4:] == [83, 4, 8, 256]
+        assert plan(32 * 257, 1024, 4096)[:2] == [6, 2] and plan(32 * 257, 1024, 4096)[4:] == [32, 4, 2, 0]
+        assert plan(16 * 257, 1024, 4096)[:2] == [6, 4]
+        assert L.uspace_gemm_sk_ws_bytes(64 * 334, 1024, 4096) == 80 * 3 * slab_x
+        assert L.uspace_gemm_sk_ws_bytes(32 * 257, 1024, 4096) == 128 * 2 * slab_x
+        assert L.uspace_gemm_sk_ws_bytes(30 * 256 + 500, 1024, 4096) == 128 * 2 * slab_x         # 31 tile rows + 16 strips (244 rows left)
+        assert plan(10 * 256 + 200, 1024, 4096)[:2] == [6, 4] and plan(10 * 256 + 200, 1024, 4096)[4:] == [11, 4, 0, 0]   # 200 rows left > 10 strips: an 11th tile row
+        assert L.uspace_gemm_sk_ws_bytes(10 * 256 + 200, 1024, 4096) == 48 * 4 * slab             # ... no strips: 256 KiB slabs; 44 tiles padded to 6 groups of 8
+        assert L.uspace_gemm_part_slots_k(32 * 257, 1024, 4096) == 4                              # 256-wide tiles: one stride for the whole launch
+        assert L.uspace_gemm_part_slots_k(32 * 257, 1024, 1024) == 8                              # proj stays on 256x128 tiles
+        for M, N, K in ((64 * 257, 1024, 4096), (64 * 257, 4096, 1024), (64 * 257, 3072, 1024),    # the headline: whole rounds, no tail
+                        (64 * 334, 1024, 2048), (64 * 334, 1024, 1024), (32 * 257, 3072, 1024),    # K loops below 64 tiles: the exchange costs more than it saves
+                        (64 * 334, 512, 2048), (4 * 257, 512, 2048), (24 * 257, 1024, 4096)):      # U-ViT-S; small launches; 96 tiles x 2 would idle a quarter of the CUs
+            assert plan(M, N, K)[0] != 6 and L.uspace_gemm_sk_ws_bytes(M, N, K) == 0, (M, N, K)
+        # the U-ViT workspace carries the slabs and one set of counters per GEMM launch only where a launch has a tail
+        cfg = _hip.UvitConfig(32, 2, 4, 1024, 20, 16, 4096, 0, 0, 0)
+        with_sk = {B: L.uspace_uvit_workspace_bytes(ctypes.byref(cfg), B) for B in (64, 32)}
+        assert L.uspace_gemm_set_sk(0) == 0 and L.uspace_gemm_get_sk() == 0
+        assert plan(32 * 257, 1024, 4096)[0] == 4 and L.uspace_gemm_sk_ws_bytes(32 * 257, 1024, 4096) == 0
+        assert L.uspace_gemm_part_slots_k(32 * 257, 1024, 4096) == 8
+        without = {B: L.uspace_uvit_workspace_bytes(ctypes.byref(cfg), B) for B in (64, 32)}
+        assert with_sk[64] == without[64] and with_sk[32] - without[32] >= 128 * 2 * slab_x
+        assert L.uspace_gemm_set_sk(2) < 0
+    finally:
+        L.uspace_gemm_set_sk(-1)
+    assert L.uspace_gemm_get_sk() == 1
+
+
 def test_gemm_k_split_workspace_sizes():
     """uspace_gemm_split_ws_bytes: only launches of 128x128 tiles that leave most CUs idle and have a long K are split
     (S K ranges, S * M * N fp32 partial sums): the fc2 / skip_linear shapes of the small batches; never the headline shapes."""
